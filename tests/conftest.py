@@ -1,0 +1,52 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLDEN = os.path.join(HERE, "golden")
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def nttdata():
+    """The reference's shipped cases: {id: (n, p, a, b, ab)} (cases 1-3 packed u32, case 0 from text)."""
+    cases = {}
+    tin = open(os.path.join(GOLDEN, "nttdata_0.in")).read().split()
+    n, p = int(tin[0]), int(tin[1])
+    a = np.array(tin[2:2 + n], dtype=np.uint32)
+    b = np.array(tin[2 + n:2 + 2 * n], dtype=np.uint32)
+    ab = np.array(open(os.path.join(GOLDEN, "nttdata_0.out")).read().split(), dtype=np.uint32)
+    cases[0] = (n, p, a, b, ab)
+    for cid in (1, 2, 3):
+        z = np.load(os.path.join(GOLDEN, f"nttdata_{cid}.npz"))
+        cases[cid] = (int(z["n"]), int(z["p"]), z["a"], z["b"], z["ab"])
+    return cases
+
+
+@pytest.fixture(scope="session")
+def ref_ntt_vectors():
+    return np.load(os.path.join(GOLDEN, "ref_ntt_vectors.npz"))
+
+
+@pytest.fixture(scope="session")
+def ref_polymul_vectors():
+    return np.load(os.path.join(GOLDEN, "ref_polymul_vectors.npz"))
+
+
+@pytest.fixture(scope="session")
+def crt_vectors():
+    return np.load(os.path.join(GOLDEN, "crt_vectors.npz"))
