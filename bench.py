@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: batched poly_multiply at n = 2^17 with a 32-bit NTT prime.
+
+A "step" is one pass of the hot path over one batch: B = 1024 independent products of two
+degree-(n-1) polynomials, n = 131072, p = 998244353 (BASELINE.json configs[1]), inputs and outputs
+resident in HBM.  With N GPUs every rank runs its own batch (independent units, no data-path
+collective: "weak" scaling); the barrier and the max-over-ranks time go through torch.distributed
+(RCCL when N > 1).
+
+Prints ONE JSON line on rank 0 with the driver's contract fields plus
+  roofline     -- HBM roofline of the dominant kernel, timed with HIP events inside the library on
+                  the stream the kernels run on (ntt_ctx_enable_kernel_timing)
+  cpu_baseline -- the CPU oracle's restatement of the reference's OpenMP path (main-openmp.cc) timed
+                  on this box's host cores on a bounded sample of the same workload (rank 0, N = 1)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def splitmix_fill(seed, rows, n, p):
+    import orc
+    out = np.empty((rows, n), dtype=np.uint32)
+    for r in range(rows):        # seed 0x20250711 + pair index, next() % p
+        out[r] = (orc.splitmix64_np(seed + r, n) % np.uint64(p)).astype(np.uint32)
+    return out
+
+
+def cpu_baseline(n, p, threads, budget_s):
+    """The oracle's port of main-openmp.cc (per-stage block-parallel radix-2 NTT, 64-bit Montgomery),
+    timed between the reference's Start/End stamps.  Checker code used as the reported baseline only."""
+    import orc
+    a = (orc.splitmix64_np(0x20250711, n) % np.uint64(p)).astype(np.uint64)
+    b = (orc.splitmix64_np(0x20250711 + (1 << 20), n) % np.uint64(p)).astype(np.uint64)
+    orc.poly_multiply_omp(a, b, p, threads=threads)          # warm-up
+    t0 = time.time()
+    secs, reps = 0.0, 0
+    while time.time() - t0 < budget_s and reps < 200:
+        _, s = orc.poly_multiply_omp(a, b, p, threads=threads)
+        secs += s
+        reps += 1
+    return {"value": reps / secs, "unit": "poly-mults/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} products of n={n}, p={p} (oracle port of main-openmp.cc:678-692, "
+                      f"timer between its Start/End stamps), {threads} OpenMP threads",
+            "ms_per_product": 1e3 * secs / reps}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--n", type=int, default=131072)
+    ap.add_argument("--p", type=int, default=998244353)
+    ap.add_argument("--barrett", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch                      # device memory, streams and torch.distributed: plumbing
+    import ntt_amd                    # the product: HIP kernels behind the C ABI
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    B, n, p = args.batch, args.n, args.p
+    stride = 2 * n
+    seed = 0x20250711 + rank * B          # every rank multiplies different polynomials
+    ha = splitmix_fill(seed, B, n, p)
+    hb = splitmix_fill(seed + (1 << 20), B, n, p)
+    da = torch.from_numpy(ha.view(np.int32)).cuda()
+    db = torch.from_numpy(hb.view(np.int32)).cuda()
+    dab = torch.zeros((B, stride), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+
+    ctx = ntt_amd.Context(local_rank)
+    kind = ntt_amd.BARRETT if args.barrett else ntt_amd.MONTGOMERY
+    plan = ctx.plan(p, n, B, kind)
+
+    def step():
+        plan.multiply(da, db, out=dab, batch=B, out_stride=stride)
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+
+    # spot-check the warm-up output against the oracle before timing anything (rank 0)
+    if rank == 0:
+        import orc
+        row = B - 1
+        got = dab[row, :2 * n - 1].cpu().numpy().view(np.uint32)
+        if not np.array_equal(got, orc.poly_multiply(ha[row], hb[row], p)):
+            print("bench: GPU result differs from the oracle", file=sys.stderr)
+            sys.exit(1)
+
+    ctx.enable_kernel_timing(True)
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ktimes = ctx.kernel_times()
+    ctx.enable_kernel_timing(False)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        units = world * B * args.steps
+        value = units / elapsed
+        alg_bytes = 16 * n - 4                      # read a, read b, write ab
+        # dominant kernel = largest share of device time in the timed region
+        name, (tot_ms, launches) = max(((k, v) for k, v in ktimes.items() if v[1] > 0),
+                                       key=lambda kv: kv[1][0])
+        units_per_launch = B * args.steps / launches
+        avg_ms = tot_ms / launches
+        achieved = alg_bytes * units_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(name)
+        out = {
+            "metric": "poly-mults/sec at n=2^17 (32-bit p)",
+            "value": value,
+            "unit": "poly-mults/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"batched {B}x poly_multiply, n={n}, p={p}, "
+                                   f"{'Barrett' if args.barrett else 'Montgomery'} NTT, L={plan.length} "
+                                   "(BASELINE.json configs[1]); splitmix64 coefficients, device-resident",
+                       "batch_per_gpu": B, "n": n, "p": p, "sharding": f"batch x{world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": name, "avg_launch_ms": avg_ms, "launches": launches,
+                         "units_per_launch": units_per_launch, "algorithmic_bytes_per_unit": alg_bytes,
+                         "pipeline_achieved": value / world * alg_bytes / 1e9,
+                         "pipeline_frac": value / world * alg_bytes / 1e9 / HBM_PEAK_GBPS,
+                         "kernel_ms": {k: v[0] for k, v in ktimes.items() if v[1] > 0}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(16, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(n, p, threads, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    plan.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,135 @@
+/*
+ * ntt_amd.h -- C ABI of the MI355X-native NTT polynomial-multiplication engine (libntt_amd.so).
+ *
+ * This is the drop-in boundary for the reference's one hot path: the
+ * teacher-harness contract poly_multiply(a, b, ab, n, p) with fRead / fCheck / fWrite around it.
+ * The reference has no FFI layer; each declaration cites the reference item it replaces
+ * (file:line relative to the reference tree).  Plain pointers and sizes only; no exceptions
+ * cross this boundary; every function except poly_multiply returns an int status.
+ *
+ * Pointer arguments documented "host or device" are classified with hipPointerGetAttributes:
+ * device pointers are used in place (no copies, asynchronous on the context's stream), host
+ * pointers are staged through device memory and the call returns after the D2H copy.
+ *
+ * There is NO CPU fallback: without a usable gfx950 device every compute entry point fails
+ * (NTT_ERR_HIP), and poly_multiply aborts with a message.
+ */
+#ifndef NTT_AMD_H
+#define NTT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    NTT_OK = 0,
+    NTT_ERR_INVALID = 1,      /* bad argument (null pointer, n <= 0, batch <= 0, ...) */
+    NTT_ERR_UNSUPPORTED = 2,  /* p not an NTT-friendly prime for this length, p >= 2^31, L too large */
+    NTT_ERR_HIP = 3,          /* HIP runtime failure; ntt_last_error() holds hipGetErrorString */
+    NTT_ERR_NOMEM = 4,
+    NTT_ERR_IO = 5,           /* fixture file missing / malformed */
+    NTT_ERR_MISMATCH = 6      /* ntt_check_case: result differs from the .out file */
+} ntt_status;
+
+/* Modular-multiplication flavour of a plan.  Both give canonical residues in [0,p) and hence
+ * bit-identical results.  MONTGOMERY replaces class montgomery (main-montgomery.cc:133-234,
+ * REDC :170-181) with 32-bit lanes, R = 2^32; BARRETT replaces class Barrett
+ * (main-barrett.cc:130-172, reduce :145-150) with 32-bit lanes and per-twiddle precomputed
+ * quotients. */
+typedef enum { NTT_MODMUL_MONTGOMERY = 0, NTT_MODMUL_BARRETT = 1 } ntt_modmul_kind;
+
+typedef struct ntt_ctx ntt_ctx;     /* one GPU + one stream; thread-safe per handle */
+typedef struct ntt_plan ntt_plan;   /* (p, n, L, batch capacity, twiddle tables, work buffers) */
+
+/* ---- 1. the reference's own entry point --------------------------------------------------- */
+
+/* Replaces: void poly_multiply(int *a, int *b, int *ab, int n, int p)
+ *           main-montgomery.cc:71-77 (identical in every .cc), called at :337-338.
+ * Same signature and ownership: a, b hold n values in [0,p) (host memory), ab receives the
+ * 2n-1 product coefficients in [0,p); entries >= 2n-1 are not touched.  Overwrite semantics
+ * (the reference accumulates into a pre-zeroed ab; with ab zeroed by the caller, as the harness
+ * does at :314, the results are identical).  p must be an NTT-friendly prime < 2^31.
+ * One-shot wrapper over a lazily created process-global context on device 0 with cached plans;
+ * it cannot report errors through its signature, so it prints a message and aborts on failure. */
+void poly_multiply(int *a, int *b, int *ab, int n, int p);
+
+/* ---- 2. handle API ------------------------------------------------------------------------ */
+
+/* Create a context on the given HIP device(s).  One process drives one GPU (multi-GPU runs are
+ * one process per GPU); ndev must be 1.  No reference counterpart (the reference's CUDA files
+ * use the implicit device, e.g. main-montgomery-GPU.cu:383). */
+int ntt_ctx_create(const int *device_ids, int ndev, ntt_ctx **out_ctx);
+int ntt_ctx_destroy(ntt_ctx *ctx);
+/* Use an existing hipStream_t (passed as void*) for all work of this context; NULL restores the
+ * context's own stream.  ntt_ctx_stream returns the stream in use (as void*). */
+int ntt_ctx_set_stream(ntt_ctx *ctx, void *hip_stream);
+void *ntt_ctx_stream(ntt_ctx *ctx);
+int ntt_ctx_synchronize(ntt_ctx *ctx);
+
+/* Build a plan for products of two length-n polynomials modulo the prime p (< 2^31):
+ * chooses L = the smallest power of two >= 2n (main-barrett.cc:249-253; the power-of-four rule
+ * of main-montgomery.cc:317-321 gives the same first 2n-1 coefficients), finds a primitive root
+ * (the reference hard-codes g = 3, main-montgomery.cc:257; any generator gives the same
+ * canonical result), builds the twiddle tables in HBM and sizes the work buffers for `batch`
+ * simultaneous products.  Replaces the per-call setup of main-montgomery.cc:315-321 and the
+ * per-stage power() calls of NTT_iterative :262-268. */
+int ntt_plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind, ntt_plan **out_plan);
+int ntt_plan_destroy(ntt_plan *plan);
+/* Transform length L of the plan. */
+int ntt_plan_length(const ntt_plan *plan);
+
+/* batch products: a, b are [batch][n] u32 (row stride n), ab is [batch][2n-1] stored with row
+ * stride `ab_stride` elements (>= 2n-1; SURVEY 8d uses 2n).  Host or device pointers.
+ * Replaces the harness multiply body main-montgomery.cc:326-351 / main-barrett.cc:258-282
+ * (pad, NTT, NTT, pointwise, inverse NTT, copy 2n-1). */
+int ntt_poly_multiply_batched(ntt_plan *plan, const uint32_t *a, const uint32_t *b, uint32_t *ab,
+                              size_t ab_stride, int batch);
+
+/* Batched in-place transforms of length L = ntt_plan_length(plan): data is [batch][L] u32,
+ * natural order in, natural order out, canonical residues, forward root g^((p-1)/L) with the
+ * plan's generator g (g = 3 for the reference's primes), inverse scaled by L^-1.
+ * Replaces NTT_iterative(a, len, p, +1 / -1, m): main-montgomery.cc:255-295,
+ * main-barrett.cc:193-228 (including bit_reverse :238-253). */
+int ntt_forward(ntt_plan *plan, uint32_t *data, int batch);
+int ntt_inverse(ntt_plan *plan, uint32_t *data, int batch);
+
+/* Large-modulus product through the four fixed 30/31-bit primes
+ * {1004535809, 1224736769, 469762049, 998244353} and a GPU CRT merge: a, b hold n values
+ * < p64 (p64 < 2^62 and n * p64^2 < the product of the four primes), ab receives 2n-1 values
+ * in [0,p64).  Host or device pointers.
+ * Replaces the p_ >= 2^50 branch of main-openmp.cc:693-711: CRT_parallel :424-440,
+ * crt_precompute :449-466, CRT_combine_parallel :468-485 (twins main.cc:813-951). */
+int ntt_crt_multiply(ntt_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *ab, int n,
+                     uint64_t p64);
+
+/* Per-kernel timing (HIP events on the context's stream) for bench.py's roofline block.
+ * With timing enabled every kernel launch is bracketed by events; ntt_ctx_kernel_time returns
+ * the accumulated milliseconds and launch count of kernel `index` (0 .. count-1) and its name;
+ * returns NTT_ERR_INVALID past the end.  Reset with ntt_ctx_enable_kernel_timing(ctx, 1). */
+int ntt_ctx_enable_kernel_timing(ntt_ctx *ctx, int enable);
+int ntt_ctx_kernel_time(ntt_ctx *ctx, int index, const char **name, double *total_ms, long *launches);
+
+/* Thread-local message of the last failure in this thread ("" if none). */
+const char *ntt_last_error(void);
+
+/* ---- 3. harness helpers (reference text formats) ------------------------ */
+
+/* Replaces fRead(int*a,int*b,int*n,int*p,int id): main-montgomery.cc:15-32; u64 overload
+ * main-openmp.cc:21-40.  Reads "<dir>/<id>.in" = "n p\n a[0..n) b[0..n)".  a and b must hold
+ * `cap` elements; values are stored as u64 so the 51-bit case fits. */
+int ntt_read_case(const char *dir, int id, uint64_t *a, uint64_t *b, size_t cap, int *n, uint64_t *p);
+/* Replaces fCheck(int*ab,int n,int id): main-montgomery.cc:34-54.  Compares ab[0..2n-2] with
+ * "<dir>/<id>.out", prints the reference's verdict line verbatim, and (unlike the reference,
+ * which always exits 0) returns NTT_OK / NTT_ERR_MISMATCH / NTT_ERR_IO. */
+int ntt_check_case(const char *dir, int id, const uint64_t *ab, int n);
+/* Replaces fWrite(int*ab,int n,int id): main-montgomery.cc:56-69.  Writes "<dir>/<id>.out",
+ * one decimal per line. */
+int ntt_write_case(const char *dir, int id, const uint64_t *ab, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NTT_AMD_H */

@@ -1,0 +1,234 @@
+"""ntt_amd -- MI355X-native NTT polynomial multiplication.
+
+Thin ctypes binding over the C ABI of ``libntt_amd.so`` (``include/ntt_amd.h``); all compute is
+hand-written HIP for gfx950 inside that library.  There is no CPU fallback: if the shared library
+is missing this module raises at import, and every compute call fails without a gfx950 device.
+
+The Python surface mirrors the reference harness (``main-montgomery.cc``):
+
+* ``poly_multiply(a, b, p)``                 <- ``poly_multiply(int*a,int*b,int*ab,int n,int p)``
+* ``read_case / check_case / write_case``    <- ``fRead / fCheck / fWrite``
+* ``Context`` / ``Plan``                     <- the handle API for batched, device-resident work
+
+Arrays may be numpy arrays (host memory; the library stages them) or objects exposing
+``data_ptr()`` (torch CUDA tensors: used in place on the context's stream).
+"""
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+
+# PyTorch-ROCm bundles its own HIP + HSA runtimes.  Two HSA runtimes cannot drive the GPU from one
+# process; if torch is loaded AFTER this library it brings a second one and torch.cuda then reports
+# "No HIP GPUs are available".  Loaded first, torch's HSA runtime (same soname) is the one the
+# system HIP runtime under libntt_amd.so binds to, and both work side by side.  So: torch first.
+if importlib.util.find_spec("torch") is not None:
+    import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libntt_amd.so")
+
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM, ERR_IO, ERR_MISMATCH = range(7)
+MONTGOMERY, BARRETT = 0, 1
+
+EXPORTED_SYMBOLS = (
+    "poly_multiply", "ntt_ctx_create", "ntt_ctx_destroy", "ntt_ctx_set_stream", "ntt_ctx_stream",
+    "ntt_ctx_synchronize", "ntt_plan_create", "ntt_plan_destroy", "ntt_plan_length",
+    "ntt_poly_multiply_batched", "ntt_forward", "ntt_inverse", "ntt_crt_multiply",
+    "ntt_ctx_enable_kernel_timing", "ntt_ctx_kernel_time", "ntt_last_error", "ntt_read_case",
+    "ntt_check_case", "ntt_write_case",
+)
+
+
+class NttError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ntt_amd error {code}: {msg}")
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            f"{_LIB_PATH} is missing: build it with `make -C ntt_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(_LIB_PATH)
+    vp, u32, u64, i32, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_size_t
+    lib.poly_multiply.argtypes = [vp, vp, vp, i32, i32]
+    lib.poly_multiply.restype = None
+    lib.ntt_ctx_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
+    lib.ntt_ctx_destroy.argtypes = [vp]
+    lib.ntt_ctx_set_stream.argtypes = [vp, vp]
+    lib.ntt_ctx_stream.argtypes = [vp]
+    lib.ntt_ctx_stream.restype = vp
+    lib.ntt_ctx_synchronize.argtypes = [vp]
+    lib.ntt_plan_create.argtypes = [vp, u32, i32, i32, i32, C.POINTER(vp)]
+    lib.ntt_plan_destroy.argtypes = [vp]
+    lib.ntt_plan_length.argtypes = [vp]
+    lib.ntt_poly_multiply_batched.argtypes = [vp, vp, vp, vp, sz, i32]
+    lib.ntt_forward.argtypes = [vp, vp, i32]
+    lib.ntt_inverse.argtypes = [vp, vp, i32]
+    lib.ntt_crt_multiply.argtypes = [vp, vp, vp, vp, i32, u64]
+    lib.ntt_ctx_enable_kernel_timing.argtypes = [vp, i32]
+    lib.ntt_ctx_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_long)]
+    lib.ntt_last_error.restype = C.c_char_p
+    lib.ntt_read_case.argtypes = [C.c_char_p, i32, vp, vp, sz, C.POINTER(i32), C.POINTER(u64)]
+    lib.ntt_check_case.argtypes = [C.c_char_p, i32, vp, i32]
+    lib.ntt_write_case.argtypes = [C.c_char_p, i32, vp, i32]
+    return lib
+
+
+_lib = _load()
+
+
+def _check(rc):
+    if rc != OK:
+        raise NttError(rc, _lib.ntt_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(x, dtype):
+    """Raw address of a numpy array (host) or of an object with data_ptr() (device tensor)."""
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    if not isinstance(x, np.ndarray) or x.dtype != dtype or not x.flags["C_CONTIGUOUS"]:
+        raise TypeError(f"expected a C-contiguous numpy array of {np.dtype(dtype)} or a device tensor")
+    return C.c_void_p(x.ctypes.data)
+
+
+class Context:
+    """One GPU + one stream (``ntt_ctx``)."""
+
+    def __init__(self, device=0):
+        dev = C.c_int(device)
+        h = C.c_void_p()
+        _check(_lib.ntt_ctx_create(C.byref(dev), 1, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h:
+            _lib.ntt_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        _check(_lib.ntt_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    @property
+    def stream(self):
+        return _lib.ntt_ctx_stream(self._h)
+
+    def synchronize(self):
+        _check(_lib.ntt_ctx_synchronize(self._h))
+
+    def plan(self, p, n, batch=1, kind=MONTGOMERY):
+        return Plan(self, p, n, batch, kind)
+
+    def crt_multiply(self, a, b, p64, out=None):
+        """Large-modulus product (main-openmp.cc:693-711): a, b uint64 < p64; returns 2n-1 uint64."""
+        n = int(a.shape[-1]) if hasattr(a, "shape") else len(a)
+        if out is None:
+            out = np.zeros(2 * n - 1, dtype=np.uint64)
+        _check(_lib.ntt_crt_multiply(self._h, _ptr(a, np.uint64), _ptr(b, np.uint64),
+                                     _ptr(out, np.uint64), n, int(p64)))
+        return out
+
+    def enable_kernel_timing(self, enable=True):
+        _check(_lib.ntt_ctx_enable_kernel_timing(self._h, 1 if enable else 0))
+
+    def kernel_times(self):
+        """{kernel name: (total ms, launches)} accumulated since timing was (re-)enabled."""
+        out = {}
+        i = 0
+        while True:
+            name, ms, cnt = C.c_char_p(), C.c_double(), C.c_long()
+            rc = _lib.ntt_ctx_kernel_time(self._h, i, C.byref(name), C.byref(ms), C.byref(cnt))
+            if rc != OK:
+                break
+            out[name.value.decode()] = (ms.value, cnt.value)
+            i += 1
+        return out
+
+
+class Plan:
+    """Products of two length-n polynomials mod the prime p (``ntt_plan``)."""
+
+    def __init__(self, ctx, p, n, batch=1, kind=MONTGOMERY):
+        h = C.c_void_p()
+        _check(_lib.ntt_plan_create(ctx._h, int(p), int(n), int(batch), int(kind), C.byref(h)))
+        self._h = h
+        self.ctx, self.p, self.n, self.batch, self.kind = ctx, int(p), int(n), int(batch), kind
+        self.length = _lib.ntt_plan_length(h)
+
+    def close(self):
+        if self._h:
+            _lib.ntt_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def multiply(self, a, b, out=None, batch=None, out_stride=None):
+        """a, b: [batch, n] uint32 -> [batch, out_stride] uint32 holding 2n-1 coefficients per row."""
+        if batch is None:
+            batch = int(a.shape[0]) if getattr(a, "ndim", 1) == 2 or (hasattr(a, "dim") and a.dim() == 2) else 1
+        if out_stride is None:
+            out_stride = 2 * self.n - 1
+        if out is None:
+            out = np.zeros((batch, out_stride), dtype=np.uint32)
+        _check(_lib.ntt_poly_multiply_batched(self._h, _ptr(a, np.uint32), _ptr(b, np.uint32),
+                                              _ptr(out, np.uint32), out_stride, batch))
+        return out
+
+    def forward(self, data, batch=1):
+        _check(_lib.ntt_forward(self._h, _ptr(data, np.uint32), batch))
+        return data
+
+    def inverse(self, data, batch=1):
+        _check(_lib.ntt_inverse(self._h, _ptr(data, np.uint32), batch))
+        return data
+
+
+def poly_multiply(a, b, p):
+    """The reference entry point: int32 arrays a, b of length n -> int32 array of 2n-1 products mod p."""
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    b = np.ascontiguousarray(b, dtype=np.int32)
+    n = a.size
+    ab = np.zeros(2 * n - 1, dtype=np.int32)
+    _lib.poly_multiply(a.ctypes.data, b.ctypes.data, ab.ctypes.data, n, int(p))
+    return ab
+
+
+def read_case(directory, case_id, cap=1 << 22):
+    a = np.zeros(cap, dtype=np.uint64)
+    b = np.zeros(cap, dtype=np.uint64)
+    n, p = C.c_int(), C.c_uint64()
+    _check(_lib.ntt_read_case(str(directory).encode(), case_id, a.ctypes.data, b.ctypes.data, cap,
+                              C.byref(n), C.byref(p)))
+    return n.value, p.value, a[:n.value].copy(), b[:n.value].copy()
+
+
+def check_case(directory, case_id, ab):
+    """Prints the reference's verdict line; returns True / False; raises on I/O errors."""
+    ab = np.ascontiguousarray(ab, dtype=np.uint64)
+    n = (ab.size + 1) // 2
+    rc = _lib.ntt_check_case(str(directory).encode(), case_id, ab.ctypes.data, n)
+    if rc == ERR_MISMATCH:
+        return False
+    _check(rc)
+    return True
+
+
+def write_case(directory, case_id, ab):
+    ab = np.ascontiguousarray(ab, dtype=np.uint64)
+    n = (ab.size + 1) // 2
+    _check(_lib.ntt_write_case(str(directory).encode(), case_id, ab.ctypes.data, n))

@@ -1,0 +1,176 @@
+// crt.cpp -- large-modulus product through four 30/31-bit primes and a GPU CRT merge, and the
+// reference's one-shot poly_multiply entry point.
+//
+// Replaces the p_ >= 2^50 branch of main-openmp.cc:693-711 (CRT_parallel :424-440, crt_precompute
+// :449-466, CRT_combine_parallel :468-485).  The reference gives each prime to an OpenMP thread
+// (or an MPI rank, main-mpi.cc:657-660) and merges on one thread team with 128-bit `%`; here the
+// four residue products run back to back on one GPU through the batched NTT path and the merge is
+// the Garner/Horner kernel of kernels_misc.hip.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/ntt_amd.h"
+#include "engine.hpp"
+
+namespace ntt {
+
+static const uint32_t kCrtMods[4] = {1004535809u, 1224736769u, 469762049u, 998244353u};   // main-openmp.cc:654
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return ntt::fail(NTT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+void crt_release(ntt_ctx *ctx)
+{
+    CrtWorkspace &w = ctx->crt;
+    for (auto &pl : w.plans) {
+        if (pl) ntt_plan_destroy(pl);
+        pl = nullptr;
+    }
+    w.ra.release(); w.rb.release(); w.res.release();
+    w.a64.release(); w.b64.release(); w.out64.release();
+    w.n = 0;
+}
+
+static int make_consts(uint64_t p64, CrtConsts &cc)
+{
+    for (int k = 0; k < 4; ++k) {
+        CrtPrime &c = cc.prime[k];
+        c.mp = make_mod_params(kCrtMods[k]);
+        c.one = Barrett32::make_tw(1, c.mp);
+        c.two32 = Barrett32::make_tw((uint32_t)((1ULL << 32) % kCrtMods[k]), c.mp);
+    }
+    for (int i = 0; i < 4; ++i)
+        for (int j = i + 1; j < 4; ++j) {
+            const uint32_t mj = kCrtMods[j];
+            const uint32_t inv = h_powmod(kCrtMods[i] % mj, mj - 2, mj);
+            cc.inv[i][j] = Barrett32::make_tw(inv, cc.prime[j].mp);
+        }
+    cc.p64 = p64;
+    uint64_t inv = 1;                                    // Newton: p64^-1 mod 2^64
+    for (int i = 0; i < 6; ++i) inv *= 2 - p64 * inv;
+    cc.nprime64 = 0 - inv;
+    for (int k = 0; k < 4; ++k)
+        cc.mR[k] = (uint64_t)((((unsigned __int128)(kCrtMods[k] % p64)) << 64) % p64);
+    return NTT_OK;
+}
+
+}  // namespace ntt
+
+using namespace ntt;
+
+extern "C" int ntt_crt_multiply(ntt_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *ab, int n,
+                                uint64_t p64)
+{
+    if (!ctx || !a || !b || !ab) return fail(NTT_ERR_INVALID, "ntt_crt_multiply: null argument");
+    if (n <= 0) return fail(NTT_ERR_INVALID, "ntt_crt_multiply: n must be positive");
+    if ((p64 & 1) == 0 || p64 < 3 || p64 >= (1ULL << 62))
+        return fail(NTT_ERR_UNSUPPORTED, "ntt_crt_multiply: p64 must be odd and below 2^62");
+    // exactness: every true coefficient < n * (p64-1)^2 must be below M = prod(m_k) (~2^119.6)
+    {
+        unsigned __int128 M = 1;
+        for (uint32_t m : kCrtMods) M *= m;
+        const unsigned __int128 sq = (unsigned __int128)(p64 - 1) * (p64 - 1);
+        if (sq > M / (unsigned)n)
+            return fail(NTT_ERR_UNSUPPORTED, "ntt_crt_multiply: n * p64^2 exceeds the product of the four CRT primes");
+    }
+    if (n > (1 << 22)) return fail(NTT_ERR_UNSUPPORTED, "ntt_crt_multiply: n too large for the 2^23-adic prime 998244353");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    CrtWorkspace &w = ctx->crt;
+    const size_t N = (size_t)n, out_len = 2 * N - 1;
+    if (w.n != n) {
+        crt_release(ctx);
+        for (int k = 0; k < 4; ++k) {
+            int rc = ntt_plan_create(ctx, kCrtMods[k], n, 1, NTT_MODMUL_MONTGOMERY, &w.plans[k]);
+            if (rc) { crt_release(ctx); return rc; }
+        }
+        w.n = n;
+    }
+    int rc = w.ra.ensure(4 * N * 4);
+    if (!rc) rc = w.rb.ensure(4 * N * 4);
+    if (!rc) rc = w.res.ensure(4 * out_len * 4);
+    if (rc) return rc;
+    const uint64_t *da = a, *db = b;
+    uint64_t *dout = ab;
+    const bool dev_a = is_device_ptr(a), dev_b = is_device_ptr(b), dev_o = is_device_ptr(ab);
+    if (!dev_a) {
+        if ((rc = w.a64.ensure(N * 8))) return rc;
+        HIP_TRY(hipMemcpyAsync(w.a64.ptr, a, N * 8, hipMemcpyHostToDevice, ctx->stream));
+        da = static_cast<const uint64_t *>(w.a64.ptr);
+    }
+    if (!dev_b) {
+        if ((rc = w.b64.ensure(N * 8))) return rc;
+        HIP_TRY(hipMemcpyAsync(w.b64.ptr, b, N * 8, hipMemcpyHostToDevice, ctx->stream));
+        db = static_cast<const uint64_t *>(w.b64.ptr);
+    }
+    if (!dev_o) {
+        if ((rc = w.out64.ensure(out_len * 8))) return rc;
+        dout = static_cast<uint64_t *>(w.out64.ptr);
+    }
+    CrtConsts cc{};
+    make_consts(p64, cc);
+    uint32_t *ra = static_cast<uint32_t *>(w.ra.ptr), *rb = static_cast<uint32_t *>(w.rb.ptr);
+    uint32_t *res = static_cast<uint32_t *>(w.res.ptr);
+    const uint32_t *rows[4];
+    for (int k = 0; k < 4; ++k) {
+        ctx->begin(K_CRT_REDUCE);
+        launch_crt_reduce(da, ra + k * N, N, cc.prime[k], ctx->stream);
+        launch_crt_reduce(db, rb + k * N, N, cc.prime[k], ctx->stream);
+        ctx->end();
+        rc = multiply_device_any(w.plans[k], ra + k * N, rb + k * N, res + k * out_len, out_len, 1);
+        if (rc) return rc;
+        rows[k] = res + k * out_len;
+    }
+    ctx->begin(K_CRT_MERGE);
+    launch_crt_merge(rows, dout, out_len, cc, ctx->stream);
+    ctx->end();
+    HIP_TRY(hipGetLastError());
+    if (!dev_o) {
+        HIP_TRY(hipMemcpyAsync(ab, dout, out_len * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    } else if (!dev_a || !dev_b) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return NTT_OK;
+}
+
+// ---- the reference's entry point ---------------------------------------------------------------------
+static ntt_ctx *g_ctx = nullptr;
+static std::mutex g_mu;
+
+extern "C" void poly_multiply(int *a, int *b, int *ab, int n, int p)
+{
+    auto die = [](const char *what) {
+        std::fprintf(stderr, "ntt_amd: poly_multiply failed: %s: %s\n", what, ntt_last_error());
+        std::abort();
+    };
+    if (!a || !b || !ab || n <= 0 || p <= 0) {
+        set_error("bad argument");
+        die("arguments");
+    }
+    ntt_plan *pl = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_ctx) {
+            int dev = 0;
+            if (ntt_ctx_create(&dev, 1, &g_ctx) != NTT_OK) die("ntt_ctx_create");
+        }
+        const std::array<uint64_t, 3> key{(uint64_t)(uint32_t)p, (uint64_t)n, (uint64_t)NTT_MODMUL_MONTGOMERY};
+        auto it = g_ctx->plan_cache.find(key);
+        if (it == g_ctx->plan_cache.end()) {
+            if (ntt_plan_create(g_ctx, (uint32_t)p, n, 1, NTT_MODMUL_MONTGOMERY, &pl) != NTT_OK) die("ntt_plan_create");
+            g_ctx->plan_cache[key] = pl;
+        } else {
+            pl = it->second;
+        }
+    }
+    // int and uint32_t share their representation for values in [0, p), p < 2^31
+    if (ntt_poly_multiply_batched(pl, reinterpret_cast<const uint32_t *>(a), reinterpret_cast<const uint32_t *>(b),
+                                  reinterpret_cast<uint32_t *>(ab), (size_t)2 * n - 1, 1) != NTT_OK)
+        die("ntt_poly_multiply_batched");
+}

@@ -1,0 +1,99 @@
+// device_ntt.hpp -- register-resident butterflies shared by the gfx950 kernels.
+//
+// Replaces the inner loop of NTT_iterative (main-montgomery.cc:270-282 / main-barrett.cc:206-217):
+// there every butterfly does two modular multiplications (value * twiddle and the running
+// twiddle update) and two `%` divisions; here twiddles are constants (SGPR operands or table
+// loads), a butterfly is one lazy modular multiplication, one add and one subtract, and a
+// thread keeps 2^k points in VGPRs for k stages before anything is written back.
+#pragma once
+#include "kernels.hpp"
+
+namespace ntt {
+
+template <class MM, bool LAZY>
+struct Ops {
+    using tw_t = typename MM::tw_t;
+    // value range invariant: [0, 2p) when LAZY, [0, p) otherwise
+    static __device__ __forceinline__ uint32_t bound(const ModParams &m) { return LAZY ? m.p2 : m.p; }
+    static __device__ __forceinline__ uint32_t add(uint32_t u, uint32_t v, const ModParams &m)
+    {
+        return csub(u + v, bound(m));
+    }
+    // u - v + bound, in (0, 2*bound): valid as the variable operand of mul_tw without reduction
+    static __device__ __forceinline__ uint32_t sub_raw(uint32_t u, uint32_t v, const ModParams &m)
+    {
+        return u - v + bound(m);
+    }
+    static __device__ __forceinline__ uint32_t sub(uint32_t u, uint32_t v, const ModParams &m)
+    {
+        return csub(sub_raw(u, v, m), bound(m));
+    }
+    static __device__ __forceinline__ uint32_t mul_tw(uint32_t x, tw_t w, const ModParams &m)
+    {
+        uint32_t r = MM::mul_tw(x, w, m);             // [0, 2p)
+        return LAZY ? r : csub(r, m.p);
+    }
+    static __device__ __forceinline__ uint32_t canon(uint32_t x, const ModParams &m)
+    {
+        return LAZY ? csub(x, m.p) : x;
+    }
+    // variable * variable (pointwise product).  Montgomery: result carries a factor R^-1 that
+    // the host folds into the inverse scale constant.
+    static __device__ __forceinline__ uint32_t mul(uint32_t a, uint32_t b, const ModParams &m)
+    {
+        if constexpr (MM::kMontgomery) {
+            uint32_t r = MM::mul_raw(a, b, m);        // a*b < 4p^2 <= 2^32 p when LAZY (4p <= 2^32)
+            return LAZY ? r : csub(r, m.p);
+        } else {
+            return MM::mul_raw(canon(a, m), canon(b, m), m);
+        }
+    }
+};
+
+__host__ __device__ constexpr int bitrev_c(int x, int bits)
+{
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+// In-register N-point transform, N = 2^LOGN <= 64: natural order in, natural order out,
+// X[k] = sum_j x[j] * w^(jk) with w = roots.w[32/(N/2)] (i.e. the primitive N-th root whose
+// powers are the stride-(64/N) entries of the w_64 table; forward or inverse table).
+// Decimation in frequency; the final bit reversal is a compile-time register renaming.
+// HALF: x[j] == 0 for j >= N/2 (zero-padded operand), the first stage then needs no add/sub.
+template <class MM, bool LAZY, int LOGN, bool HALF>
+__device__ __forceinline__ void reg_ntt(uint32_t (&x)[1 << LOGN], const Roots64<MM> &roots,
+                                        const ModParams &m)
+{
+    using O = Ops<MM, LAZY>;
+    constexpr int N = 1 << LOGN;
+    if constexpr (LOGN == 0) return;
+#pragma unroll
+    for (int s = 0; s < LOGN; ++s) {
+        const int half = N >> (s + 1);
+        const int step = 32 / half;                   // w_(2*half)^j = w_64^(j*step)
+#pragma unroll
+        for (int blk = 0; blk < N; blk += 2 * half) {
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                uint32_t u = x[blk + j], v = x[blk + j + half];
+                if (HALF && s == 0) {
+                    // v == 0: sum = u, difference = u
+                    x[blk + j + half] = (j == 0) ? u : O::mul_tw(u, roots.w[j * step], m);
+                } else {
+                    x[blk + j] = O::add(u, v, m);
+                    x[blk + j + half] = (j == 0) ? O::sub(u, v, m)
+                                                 : O::mul_tw(O::sub_raw(u, v, m), roots.w[j * step], m);
+                }
+            }
+        }
+    }
+    uint32_t y[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[bitrev_c(i, LOGN)] = x[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = y[i];
+}
+
+}  // namespace ntt

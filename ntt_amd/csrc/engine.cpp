@@ -1,0 +1,634 @@
+// engine.cpp -- contexts, plans (root search, twiddle tables, work buffers) and the launch
+// sequences of the NTT multiply path.  Host C++ over the HIP runtime; the kernels live in
+// kernels_*.hip.  See include/ntt_amd.h for the reference interface each entry point replaces.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+
+#include "../../include/ntt_amd.h"
+
+namespace ntt {
+
+const char *const kKernelNames[K_COUNT] = {"col_fwd", "row_mul", "col_inv", "row_fwd", "row_inv",
+                                           "small", "permute", "crt_reduce", "crt_merge"};
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+const char *last_error_cstr() { return g_err.c_str(); }
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return ntt::fail(NTT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+int DeviceBuffer::ensure(size_t need)
+{
+    if (need <= bytes) return NTT_OK;
+    if (ptr) {
+        HIP_TRY(hipFree(ptr));
+        ptr = nullptr;
+        bytes = 0;
+    }
+    hipError_t e = hipMalloc(&ptr, need);
+    if (e != hipSuccess) {
+        ptr = nullptr;
+        return fail(e == hipErrorOutOfMemory ? NTT_ERR_NOMEM : NTT_ERR_HIP,
+                    std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    bytes = need;
+    return NTT_OK;
+}
+void DeviceBuffer::release()
+{
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+}
+
+// Device or host?  hipPointerGetAttributes knows the allocations of THIS HIP runtime.  A pointer
+// from another HIP runtime in the same process (PyTorch bundles its own libamdhip64; both sit on
+// one HSA runtime) is unknown to it, so fall back to the HSA pointer registry, which is shared.
+bool is_device_ptr(const void *p)
+{
+    hipPointerAttribute_t at{};
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e == hipSuccess && (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged)) return true;
+    if (e != hipSuccess) (void)hipGetLastError();   // unregistered memory reports an error: clear it
+    hsa_amd_pointer_info_t info{};
+    info.size = sizeof(info);
+    if (hsa_amd_pointer_info(const_cast<void *>(p), &info, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS)
+        return false;
+    if (info.type != HSA_EXT_POINTER_TYPE_HSA) return false;
+    hsa_device_type_t dt = HSA_DEVICE_TYPE_CPU;
+    if (hsa_agent_get_info(info.agentOwner, HSA_AGENT_INFO_DEVICE, &dt) != HSA_STATUS_SUCCESS) return false;
+    return dt == HSA_DEVICE_TYPE_GPU;
+}
+
+// ---- table construction -------------------------------------------------------------------------
+template <class MM>
+static int upload_table(ntt_plan *pl, const std::vector<typename MM::tw_t> &h, void **dptr)
+{
+    void *d = nullptr;
+    HIP_TRY(hipMalloc(&d, h.size() * sizeof(typename MM::tw_t)));
+    pl->owned.push_back(d);
+    HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(typename MM::tw_t), hipMemcpyHostToDevice));
+    *dptr = d;
+    return NTT_OK;
+}
+
+// T[k][i] = c * w^(i*k), k < rows, i < cols
+template <class MM>
+static std::vector<typename MM::tw_t> power_table(uint32_t w, uint32_t rows, uint32_t cols, uint32_t c,
+                                                  const ModParams &mp)
+{
+    std::vector<typename MM::tw_t> t((size_t)rows * cols);
+    uint32_t wk = 1;                                   // w^k
+    for (uint32_t k = 0; k < rows; ++k) {
+        uint32_t cur = c;
+        for (uint32_t i = 0; i < cols; ++i) {
+            t[(size_t)k * cols + i] = MM::make_tw(cur, mp);
+            cur = h_mulmod(cur, wk, mp.p);
+        }
+        wk = h_mulmod(wk, w, mp.p);
+    }
+    return t;
+}
+
+template <class MM>
+static std::vector<unsigned char> bytes_of_tw(uint32_t v, const ModParams &mp)
+{
+    typename MM::tw_t t = MM::make_tw(v, mp);
+    std::vector<unsigned char> b(sizeof(t));
+    std::memcpy(b.data(), &t, sizeof(t));
+    return b;
+}
+
+template <class MM>
+static int build_tables(ntt_plan *pl)
+{
+    const ModParams &mp = pl->mp;
+    const uint32_t p = pl->p, L = pl->L;
+    const uint32_t wL = h_powmod(pl->g, (p - 1) / L, p);
+    const uint32_t iwL = h_powmod(wL, p - 2, p);
+    const uint32_t invL = h_powmod(L % p, p - 2, p);
+    // Montgomery's pointwise product carries R^-1: fold R into the multiply-path scale
+    const uint32_t scale_mul = MM::kMontgomery ? h_mulmod(invL, mp.r1, p) : invL;
+    pl->scale_mul = bytes_of_tw<MM>(scale_mul, mp);
+    pl->scale_plain = bytes_of_tw<MM>(invL, mp);
+
+    if (pl->logL <= kRowLog) {
+        std::vector<typename MM::tw_t> w(std::max<uint32_t>(L / 2, 1)), iw(std::max<uint32_t>(L / 2, 1));
+        uint32_t c = 1, ic = 1;
+        for (uint32_t j = 0; j < L / 2; ++j) {
+            w[j] = MM::make_tw(c, mp);
+            iw[j] = MM::make_tw(ic, mp);
+            c = h_mulmod(c, wL, p);
+            ic = h_mulmod(ic, iwL, p);
+        }
+        int rc = upload_table<MM>(pl, w, &pl->small_w);
+        if (rc) return rc;
+        return upload_table<MM>(pl, iw, &pl->small_iw);
+    }
+
+    // roots of the 64-point register transform
+    Roots64<MM> r{}, ir{};
+    const uint32_t w64 = h_powmod(wL, L / 64, p), iw64 = h_powmod(iwL, L / 64, p);
+    uint32_t c = 1, ic = 1;
+    for (int j = 0; j < 32; ++j) {
+        r.w[j] = MM::make_tw(c, mp);
+        ir.w[j] = MM::make_tw(ic, mp);
+        c = h_mulmod(c, w64, p);
+        ic = h_mulmod(ic, iw64, p);
+    }
+    pl->roots.resize(sizeof(r));
+    pl->iroots.resize(sizeof(ir));
+    std::memcpy(pl->roots.data(), &r, sizeof(r));
+    std::memcpy(pl->iroots.data(), &ir, sizeof(ir));
+
+    // column levels
+    for (int j = 0; j < pl->nlevels; ++j) {
+        const uint32_t M = 1u << pl->level_logM[j], N1 = 1u << pl->level_log[j], S = M / N1;
+        const uint32_t wM = h_powmod(wL, L / M, p), iwM = h_powmod(iwL, L / M, p);
+        const bool innermost = (j == pl->nlevels - 1);
+        int rc = upload_table<MM>(pl, power_table<MM>(wM, N1, S, 1, mp), &pl->tw_fwd[j]);
+        if (rc) return rc;
+        rc = upload_table<MM>(pl, power_table<MM>(iwM, N1, S, innermost ? scale_mul : 1, mp), &pl->tw_inv[j]);
+        if (rc) return rc;
+        if (innermost) {
+            if (scale_mul == invL) pl->tw_inv_plain = pl->tw_inv[j];
+            else {
+                rc = upload_table<MM>(pl, power_table<MM>(iwM, N1, S, invL, mp), &pl->tw_inv_plain);
+                if (rc) return rc;
+            }
+        }
+    }
+    // row tables
+    const uint32_t w4096 = h_powmod(wL, L / kRowLen, p), iw4096 = h_powmod(iwL, L / kRowLen, p);
+    const uint32_t w256 = h_powmod(w4096, 16, p), iw256 = h_powmod(iw4096, 16, p);
+    int rc = upload_table<MM>(pl, power_table<MM>(w4096, 16, 256, 1, mp), &pl->twA);
+    if (rc) return rc;
+    rc = upload_table<MM>(pl, power_table<MM>(w256, 16, 16, 1, mp), &pl->twB);
+    if (rc) return rc;
+    rc = upload_table<MM>(pl, power_table<MM>(iw4096, 16, 256, 1, mp), &pl->itwA);
+    if (rc) return rc;
+    return upload_table<MM>(pl, power_table<MM>(iw256, 16, 16, 1, mp), &pl->itwB);
+}
+
+// ---- launch sequences -----------------------------------------------------------------------------
+template <class MM>
+static void fill_roots(Roots64<MM> &dst, const std::vector<unsigned char> &src)
+{
+    std::memcpy(&dst, src.data(), sizeof(dst));
+}
+
+template <class MM>
+static void col_pass(ntt_plan *pl, int level, bool inverse, bool half_in, const uint32_t *in0,
+                     const uint32_t *in1, uint32_t *out0, uint32_t *out1, size_t in_stride,
+                     size_t out_stride, uint32_t in_len, uint32_t out_len, const void *tw,
+                     bool use_scale0, const std::vector<unsigned char> &scale0, bool canon,
+                     unsigned batch, unsigned nops)
+{
+    ColArgs<MM> a{};
+    a.in[0] = in0; a.in[1] = in1;
+    a.out[0] = out0; a.out[1] = out1;
+    a.in_stride = in_stride; a.out_stride = out_stride;
+    a.in_len = in_len; a.out_len = out_len;
+    a.logM = pl->level_logM[level];
+    a.logS = pl->level_logM[level] - pl->level_log[level];
+    a.tw = static_cast<const typename MM::tw_t *>(tw);
+    a.use_scale0 = use_scale0 ? 1 : 0;
+    if (use_scale0) std::memcpy(&a.scale0, scale0.data(), sizeof(a.scale0));
+    a.canon = canon ? 1 : 0;
+    fill_roots<MM>(a.roots, inverse ? pl->iroots : pl->roots);
+    ntt_ctx *cx = pl->ctx;
+    cx->begin(inverse ? K_COL_INV : K_COL_FWD);
+    launch_col(pl->kind, pl->lazy, pl->level_log[level], inverse, half_in, &a, pl->mp,
+               pl->L >> pl->level_log[level], batch, nops, cx->stream);
+    cx->end();
+}
+
+template <class MM>
+static void row_pass(ntt_plan *pl, int which, const uint32_t *a0, const uint32_t *b0, uint32_t *out,
+                     unsigned rows)
+{
+    RowArgs<MM> a{};
+    a.a = a0; a.b = b0; a.out = out;
+    a.twA = static_cast<const typename MM::tw_t *>(pl->twA);
+    a.twB = static_cast<const typename MM::tw_t *>(pl->twB);
+    a.itwA = static_cast<const typename MM::tw_t *>(pl->itwA);
+    a.itwB = static_cast<const typename MM::tw_t *>(pl->itwB);
+    fill_roots<MM>(a.roots, pl->roots);
+    fill_roots<MM>(a.iroots, pl->iroots);
+    ntt_ctx *cx = pl->ctx;
+    cx->begin(which == 0 ? K_ROW_MUL : which == 1 ? K_ROW_FWD : K_ROW_INV);
+    if (which == 0) launch_row_mul(pl->kind, pl->lazy, &a, pl->mp, rows, cx->stream);
+    else if (which == 1) launch_row_fwd(pl->kind, pl->lazy, &a, pl->mp, rows, cx->stream);
+    else launch_row_inv(pl->kind, pl->lazy, &a, pl->mp, rows, cx->stream);
+    cx->end();
+}
+
+template <class MM>
+static void small_pass(ntt_plan *pl, int mode, const uint32_t *a0, const uint32_t *b0, uint32_t *out,
+                       size_t in_stride, size_t out_stride, uint32_t in_len, uint32_t out_len,
+                       unsigned batch)
+{
+    SmallArgs<MM> a{};
+    a.a = a0; a.b = b0; a.out = out;
+    a.in_stride = in_stride; a.out_stride = out_stride;
+    a.in_len = in_len; a.out_len = out_len;
+    a.logL = pl->logL;
+    a.w = static_cast<const typename MM::tw_t *>(pl->small_w);
+    a.iw = static_cast<const typename MM::tw_t *>(pl->small_iw);
+    std::memcpy(&a.scale, (mode == 0 ? pl->scale_mul : pl->scale_plain).data(), sizeof(a.scale));
+    a.mode = mode;
+    ntt_ctx *cx = pl->ctx;
+    cx->begin(K_SMALL);
+    launch_small(pl->kind, pl->lazy, &a, pl->mp, batch, cx->stream);
+    cx->end();
+}
+
+// a, b, ab: DEVICE pointers.
+template <class MM>
+static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
+                           size_t ab_stride, int batch)
+{
+    const uint32_t n = (uint32_t)pl->n, L = pl->L, out_len = 2 * n - 1;
+    if (pl->logL <= kRowLog) {
+        small_pass<MM>(pl, 0, a, b, ab, n, ab_stride, n, out_len, (unsigned)batch);
+        return NTT_OK;
+    }
+    uint32_t *w0 = static_cast<uint32_t *>(pl->work0.ptr), *w1 = static_cast<uint32_t *>(pl->work1.ptr);
+    const int m = pl->nlevels;
+    for (int c0 = 0; c0 < batch; c0 += pl->chunk) {
+        const unsigned cb = (unsigned)std::min(pl->chunk, batch - c0);
+        const uint32_t *ca = a + (size_t)c0 * n, *cbp = b + (size_t)c0 * n;
+        // forward column levels (both operands per launch); level 0 reads the caller's arrays with
+        // implicit zero padding (n <= L/2: the upper half of every column is zero)
+        col_pass<MM>(pl, 0, false, true, ca, cbp, w0, w1, n, L, n, L, pl->tw_fwd[0], false, {}, false, cb, 2);
+        for (int j = 1; j < m; ++j)
+            col_pass<MM>(pl, j, false, false, w0, w1, w0, w1, L, L, L, L, pl->tw_fwd[j], false, {}, false, cb, 2);
+        // rows: forward a, forward b, pointwise, inverse
+        row_pass<MM>(pl, 0, w0, w1, w0, cb * (L >> kRowLog));
+        // inverse column levels, innermost first; the outermost writes the caller's ab
+        for (int j = m - 1; j >= 1; --j)
+            col_pass<MM>(pl, j, true, false, w0, nullptr, w0, nullptr, L, L, L, L, pl->tw_inv[j],
+                         j == m - 1, pl->scale_mul, false, cb, 1);
+        col_pass<MM>(pl, 0, true, false, w0, nullptr, ab + (size_t)c0 * ab_stride, nullptr, L, ab_stride,
+                     L, out_len, pl->tw_inv[0], m == 1, pl->scale_mul, true, cb, 1);
+    }
+    return NTT_OK;
+}
+
+int multiply_device_any(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
+                        size_t ab_stride, int batch)
+{
+    return pl->kind == NTT_MODMUL_MONTGOMERY ? multiply_device<Mont32>(pl, a, b, ab, ab_stride, batch)
+                                             : multiply_device<Barrett32>(pl, a, b, ab, ab_stride, batch);
+}
+
+static void permute_pass(ntt_plan *pl, const uint32_t *src, uint32_t *dst, bool to_natural, unsigned batch)
+{
+    PermArgs pa{};
+    pa.src = src; pa.dst = dst;
+    pa.logL = pl->logL;
+    int d = 0;
+    for (int j = 0; j < pl->nlevels; ++j) pa.level_log[d++] = pl->level_log[j];
+    pa.level_log[d++] = 4; pa.level_log[d++] = 4; pa.level_log[d++] = 4;
+    pa.nlevels = d;
+    pa.to_natural = to_natural ? 1 : 0;
+    pa.canon_p = (to_natural && pl->lazy) ? pl->p : 0;      // forward spectrum leaves the rows in [0, 2p)
+    ntt_ctx *cx = pl->ctx;
+    cx->begin(K_PERMUTE);
+    launch_permute(pa, batch, cx->stream);
+    cx->end();
+}
+
+// data: DEVICE pointer, [batch][L], transformed in place (natural order in and out).
+template <class MM>
+static int transform_device(ntt_plan *pl, uint32_t *data, int batch, bool inverse)
+{
+    const uint32_t L = pl->L;
+    if (pl->logL <= kRowLog) {
+        small_pass<MM>(pl, inverse ? 2 : 1, data, nullptr, data, L, L, L, L, (unsigned)batch);
+        return NTT_OK;
+    }
+    uint32_t *w0 = static_cast<uint32_t *>(pl->work0.ptr);
+    const int m = pl->nlevels;
+    for (int c0 = 0; c0 < batch; c0 += pl->chunk) {
+        const unsigned cb = (unsigned)std::min(pl->chunk, batch - c0);
+        uint32_t *d = data + (size_t)c0 * L;
+        if (!inverse) {
+            for (int j = 0; j < m; ++j)
+                col_pass<MM>(pl, j, false, false, d, nullptr, d, nullptr, L, L, L, L, pl->tw_fwd[j], false,
+                             {}, false, cb, 1);
+            row_pass<MM>(pl, 1, d, nullptr, w0, cb * (L >> kRowLog));
+            permute_pass(pl, w0, d, true, cb);
+        } else {
+            permute_pass(pl, d, w0, false, cb);
+            row_pass<MM>(pl, 2, w0, nullptr, w0, cb * (L >> kRowLog));
+            for (int j = m - 1; j >= 0; --j)
+                col_pass<MM>(pl, j, true, false, w0, nullptr, j == 0 ? d : w0, nullptr, L, L, L, L,
+                             j == m - 1 ? pl->tw_inv_plain : pl->tw_inv[j], j == m - 1, pl->scale_plain,
+                             j == 0, cb, 1);
+        }
+    }
+    return NTT_OK;
+}
+
+}  // namespace ntt
+
+// ================================================================================================
+// ntt_ctx
+// ================================================================================================
+hipEvent_t ntt_ctx::grab_event()
+{
+    if (!event_pool.empty()) {
+        hipEvent_t e = event_pool.back();
+        event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void ntt_ctx::begin(int id)
+{
+    if (!timing) return;
+    Stamp s{id, grab_event(), grab_event()};
+    (void)hipEventRecord(s.e0, stream);
+    stamps.push_back(s);
+}
+void ntt_ctx::end()
+{
+    if (!timing) return;
+    (void)hipEventRecord(stamps.back().e1, stream);
+}
+int ntt_ctx::fold()
+{
+    if (stamps.empty()) return NTT_OK;
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (auto &s : stamps) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s.e0, s.e1));
+        acc_ms[s.id] += ms;
+        acc_n[s.id] += 1;
+        event_pool.push_back(s.e0);
+        event_pool.push_back(s.e1);
+    }
+    stamps.clear();
+    return NTT_OK;
+}
+
+using namespace ntt;
+
+extern "C" {
+
+const char *ntt_last_error(void) { return ntt::last_error_cstr(); }
+
+int ntt_ctx_create(const int *device_ids, int ndev, ntt_ctx **out_ctx)
+{
+    if (!out_ctx) return fail(NTT_ERR_INVALID, "ntt_ctx_create: out_ctx is null");
+    *out_ctx = nullptr;
+    if (ndev != 1) return fail(NTT_ERR_UNSUPPORTED, "ntt_ctx_create: one process drives one GPU (ndev must be 1)");
+    int dev = device_ids ? device_ids[0] : 0, count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (dev < 0 || dev >= count) return fail(NTT_ERR_INVALID, "ntt_ctx_create: no such device");
+    HIP_TRY(hipSetDevice(dev));
+    hipDeviceProp_t prop{};
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(NTT_ERR_UNSUPPORTED, std::string("ntt_ctx_create: kernels are built for gfx950, device is ") + prop.gcnArchName);
+    auto *cx = new ntt_ctx();
+    cx->device = dev;
+    hipError_t e = hipStreamCreateWithFlags(&cx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete cx;
+        return fail(NTT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    cx->stream = cx->own_stream;
+    *out_ctx = cx;
+    return NTT_OK;
+}
+
+int ntt_ctx_set_stream(ntt_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return fail(NTT_ERR_INVALID, "null context");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return NTT_OK;
+}
+void *ntt_ctx_stream(ntt_ctx *ctx) { return ctx ? static_cast<void *>(ctx->stream) : nullptr; }
+
+int ntt_ctx_synchronize(ntt_ctx *ctx)
+{
+    if (!ctx) return fail(NTT_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return NTT_OK;
+}
+
+int ntt_ctx_enable_kernel_timing(ntt_ctx *ctx, int enable)
+{
+    if (!ctx) return fail(NTT_ERR_INVALID, "null context");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ctx->fold();
+    ctx->timing = enable != 0;
+    for (int i = 0; i < K_COUNT; ++i) { ctx->acc_ms[i] = 0; ctx->acc_n[i] = 0; }
+    return rc;
+}
+
+int ntt_ctx_kernel_time(ntt_ctx *ctx, int index, const char **name, double *total_ms, long *launches)
+{
+    if (!ctx || index < 0 || index >= K_COUNT) return fail(NTT_ERR_INVALID, "ntt_ctx_kernel_time: bad index");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ctx->fold();
+    if (rc) return rc;
+    if (name) *name = kKernelNames[index];
+    if (total_ms) *total_ms = ctx->acc_ms[index];
+    if (launches) *launches = ctx->acc_n[index];
+    return NTT_OK;
+}
+
+int ntt_plan_destroy(ntt_plan *pl)
+{
+    if (!pl) return NTT_OK;
+    (void)hipSetDevice(pl->ctx->device);
+    (void)hipStreamSynchronize(pl->ctx->stream);
+    for (void *d : pl->owned) (void)hipFree(d);
+    pl->work0.release();
+    pl->work1.release();
+    delete pl;
+    return NTT_OK;
+}
+
+int ntt_ctx_destroy(ntt_ctx *ctx)
+{
+    if (!ctx) return NTT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->plan_cache) ntt_plan_destroy(kv.second);
+    ctx->plan_cache.clear();
+    ntt::crt_release(ctx);
+    ctx->stage_a.release();
+    ctx->stage_b.release();
+    ctx->stage_out.release();
+    for (auto &s : ctx->stamps) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return NTT_OK;
+}
+
+int ntt_plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind, ntt_plan **out_plan)
+{
+    if (!ctx || !out_plan) return fail(NTT_ERR_INVALID, "ntt_plan_create: null argument");
+    *out_plan = nullptr;
+    if (n <= 0 || batch <= 0) return fail(NTT_ERR_INVALID, "ntt_plan_create: n and batch must be positive");
+    if (modmul_kind != NTT_MODMUL_MONTGOMERY && modmul_kind != NTT_MODMUL_BARRETT)
+        return fail(NTT_ERR_INVALID, "ntt_plan_create: unknown modmul_kind");
+    if (p >= (1u << 31) || p < 3 || !h_is_prime(p))
+        return fail(NTT_ERR_UNSUPPORTED, "ntt_plan_create: p must be an odd prime below 2^31");
+    if (n > (1 << 25)) return fail(NTT_ERR_UNSUPPORTED, "ntt_plan_create: n too large (transform length is capped at 2^26)");
+    int logL = 1;
+    while ((1u << logL) < 2u * (uint32_t)n) ++logL;
+    const uint32_t L = 1u << logL;
+    if ((p - 1) % L != 0)
+        return fail(NTT_ERR_UNSUPPORTED, "ntt_plan_create: p - 1 is not divisible by the transform length (p is not NTT-friendly for this n)");
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    std::unique_ptr<ntt_plan> pl(new ntt_plan());
+    pl->ctx = ctx;
+    pl->p = p;
+    pl->g = h_primitive_root(p);
+    pl->n = n;
+    pl->logL = logL;
+    pl->L = L;
+    pl->batch = batch;
+    pl->kind = modmul_kind;
+    pl->mp = make_mod_params(p);
+    pl->lazy = p < (1u << 30);
+    if (const char *e = std::getenv("NTT_AMD_FORCE_STRICT"))
+        if (e[0] == '1') pl->lazy = false;
+    if (logL > kRowLog) {
+        const int c = logL - kRowLog;
+        const int m = (c + kMaxColLog - 1) / kMaxColLog;
+        int logM = logL;
+        for (int j = 0; j < m; ++j) {
+            pl->level_log[j] = c / m + (j < c % m ? 1 : 0);
+            pl->level_logM[j] = logM;
+            logM -= pl->level_log[j];
+        }
+        pl->nlevels = m;
+        // work buffers: two operands per product, `chunk` products in flight.  The default keeps
+        // the intermediates of one chunk (2 * L * 4 B per product) well inside the 256 MiB
+        // Infinity Cache so that the three passes hand data over on-die.
+        size_t per = (size_t)L * sizeof(uint32_t);
+        long chunk = (long)((64u << 20) / (2 * per));
+        if (const char *e = std::getenv("NTT_AMD_CHUNK")) chunk = std::atol(e);
+        chunk = std::max<long>(1, std::min<long>(chunk, batch));
+        chunk = std::min<long>(chunk, 65535);
+        pl->chunk = (int)chunk;
+        int rc = pl->work0.ensure(per * chunk);
+        if (rc == NTT_OK) rc = pl->work1.ensure(per * chunk);
+        if (rc) { ntt_plan *raw = pl.release(); ntt_plan_destroy(raw); return rc; }
+    } else {
+        pl->chunk = batch;
+    }
+    int rc = modmul_kind == NTT_MODMUL_MONTGOMERY ? build_tables<Mont32>(pl.get())
+                                                  : build_tables<Barrett32>(pl.get());
+    if (rc) { ntt_plan *raw = pl.release(); ntt_plan_destroy(raw); return rc; }
+    *out_plan = pl.release();
+    return NTT_OK;
+}
+
+int ntt_plan_length(const ntt_plan *plan) { return plan ? (int)plan->L : 0; }
+
+int ntt_poly_multiply_batched(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
+                              size_t ab_stride, int batch)
+{
+    if (!pl || !a || !b || !ab) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched: null argument");
+    if (batch <= 0) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched: batch must be positive");
+    const size_t n = (size_t)pl->n, out_len = 2 * n - 1;
+    if (ab_stride < out_len) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched: ab_stride < 2n-1");
+    ntt_ctx *cx = pl->ctx;
+    std::lock_guard<std::mutex> lk(cx->mu);
+    HIP_TRY(hipSetDevice(cx->device));
+    const bool da = is_device_ptr(a), db = is_device_ptr(b), dab = is_device_ptr(ab);
+    const uint32_t *pa = a, *pb = b;
+    uint32_t *pab = ab;
+    const size_t in_bytes = (size_t)batch * n * 4, out_elems = ((size_t)batch - 1) * ab_stride + out_len;
+    if (!da) {
+        int rc = cx->stage_a.ensure(in_bytes);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(cx->stage_a.ptr, a, in_bytes, hipMemcpyHostToDevice, cx->stream));
+        pa = static_cast<const uint32_t *>(cx->stage_a.ptr);
+    }
+    if (!db) {
+        int rc = cx->stage_b.ensure(in_bytes);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(cx->stage_b.ptr, b, in_bytes, hipMemcpyHostToDevice, cx->stream));
+        pb = static_cast<const uint32_t *>(cx->stage_b.ptr);
+    }
+    if (!dab) {
+        int rc = cx->stage_out.ensure(out_elems * 4);
+        if (rc) return rc;
+        pab = static_cast<uint32_t *>(cx->stage_out.ptr);
+        if (ab_stride != out_len)      // keep the caller's bytes between rows: entries >= 2n-1 are not ours
+            HIP_TRY(hipMemcpyAsync(pab, ab, out_elems * 4, hipMemcpyHostToDevice, cx->stream));
+    }
+    int rc = multiply_device_any(pl, pa, pb, pab, ab_stride, batch);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    if (!dab) {
+        HIP_TRY(hipMemcpyAsync(ab, pab, out_elems * 4, hipMemcpyDeviceToHost, cx->stream));
+        HIP_TRY(hipStreamSynchronize(cx->stream));
+    } else if (!da || !db) {
+        HIP_TRY(hipStreamSynchronize(cx->stream));     // host inputs may be reused by the caller
+    }
+    return NTT_OK;
+}
+
+static int transform_entry(ntt_plan *pl, uint32_t *data, int batch, bool inverse)
+{
+    if (!pl || !data) return fail(NTT_ERR_INVALID, "ntt_forward/inverse: null argument");
+    if (batch <= 0) return fail(NTT_ERR_INVALID, "ntt_forward/inverse: batch must be positive");
+    ntt_ctx *cx = pl->ctx;
+    std::lock_guard<std::mutex> lk(cx->mu);
+    HIP_TRY(hipSetDevice(cx->device));
+    const bool dev = is_device_ptr(data);
+    uint32_t *d = data;
+    const size_t bytes = (size_t)batch * pl->L * 4;
+    if (!dev) {
+        int rc = cx->stage_a.ensure(bytes);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(cx->stage_a.ptr, data, bytes, hipMemcpyHostToDevice, cx->stream));
+        d = static_cast<uint32_t *>(cx->stage_a.ptr);
+    }
+    int rc = pl->kind == NTT_MODMUL_MONTGOMERY ? transform_device<Mont32>(pl, d, batch, inverse)
+                                               : transform_device<Barrett32>(pl, d, batch, inverse);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    if (!dev) {
+        HIP_TRY(hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, cx->stream));
+        HIP_TRY(hipStreamSynchronize(cx->stream));
+    }
+    return NTT_OK;
+}
+
+int ntt_forward(ntt_plan *plan, uint32_t *data, int batch) { return transform_entry(plan, data, batch, false); }
+int ntt_inverse(ntt_plan *plan, uint32_t *data, int batch) { return transform_entry(plan, data, batch, true); }
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+// engine.hpp -- host-side engine objects behind the C ABI (include/ntt_amd.h).
+#pragma once
+#include <array>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+struct ntt_plan;
+struct ntt_ctx;
+
+namespace ntt {
+
+enum KernelId {
+    K_COL_FWD = 0, K_ROW_MUL, K_COL_INV, K_ROW_FWD, K_ROW_INV, K_SMALL, K_PERMUTE, K_CRT_REDUCE,
+    K_CRT_MERGE, K_COUNT
+};
+extern const char *const kKernelNames[K_COUNT];
+
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need);     // grows (never shrinks); returns ntt_status
+    void release();
+};
+
+// Buffers and per-prime plans of ntt_crt_multiply, cached per context for the last n used.
+struct CrtWorkspace {
+    int n = 0;
+    ntt_plan *plans[4] = {nullptr, nullptr, nullptr, nullptr};
+    DeviceBuffer ra, rb, res, a64, b64, out64;
+};
+void crt_release(ntt_ctx *ctx);
+const char *last_error_cstr();
+bool is_device_ptr(const void *p);
+
+// device-pointer entry used by the CRT path (caller holds ctx->mu)
+int multiply_device_any(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
+                        size_t ab_stride, int batch);
+
+}  // namespace ntt
+
+struct ntt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::mutex mu;                                    // serialises calls on this handle
+
+    // per-kernel timing (bench.py roofline block)
+    bool timing = false;
+    struct Stamp { int id; hipEvent_t e0, e1; };
+    std::vector<Stamp> stamps;
+    std::vector<hipEvent_t> event_pool;
+    double acc_ms[ntt::K_COUNT] = {0};
+    long acc_n[ntt::K_COUNT] = {0};
+    void begin(int id);
+    void end();
+    int fold();                                       // sync + accumulate + recycle events
+    hipEvent_t grab_event();
+
+    // caches owned by the context
+    std::map<std::array<uint64_t, 3>, ntt_plan *> plan_cache;     // (p, n, kind): poly_multiply / CRT
+    ntt::CrtWorkspace crt;
+    ntt::DeviceBuffer stage_a, stage_b, stage_out;   // host-pointer staging
+};
+
+struct ntt_plan {
+    ntt_ctx *ctx = nullptr;
+    uint32_t p = 0, g = 0;
+    int n = 0, logL = 0, batch = 0, kind = 0, chunk = 1;
+    uint32_t L = 0;
+    bool lazy = false;
+    ntt::ModParams mp{};
+    // 4-step structure (L >= 8192): column levels, outermost first
+    int nlevels = 0;
+    int level_log[8] = {0};      // log2 N1_j
+    int level_logM[8] = {0};     // log2 M_j
+    // device tables (tw_t = u32 for Montgomery, {u32,u32} for Barrett)
+    void *tw_fwd[8] = {nullptr};
+    void *tw_inv[8] = {nullptr};        // innermost level carries the multiply scale (L^-1 [* R])
+    void *tw_inv_plain = nullptr;       // innermost level with plain L^-1 (ntt_inverse)
+    void *twA = nullptr, *twB = nullptr, *itwA = nullptr, *itwB = nullptr;
+    void *small_w = nullptr, *small_iw = nullptr;
+    // by-value kernel constants, raw bytes of Roots64<MM> / tw_t
+    std::vector<unsigned char> roots, iroots, scale_mul, scale_plain;
+    ntt::DeviceBuffer work0, work1;
+    std::vector<void *> owned;          // device allocations to free
+};

@@ -1,0 +1,97 @@
+// kernels.hpp -- launch interface between the host engine (engine.cpp) and the gfx950 kernels
+// (kernels_*.hip).  Plain structs and function declarations; no HIP types besides hipStream_t.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <hip/hip_runtime.h>
+
+#include "modarith.hpp"
+
+namespace ntt {
+
+constexpr int kRowLog = 12;              // LDS-resident row transform: 4096 points
+constexpr int kRowLen = 1 << kRowLog;
+constexpr int kMaxColLog = 6;            // register-resident column transform: up to 64 points
+
+// w_64^j, j < 32 (forward) or w_64^-j (inverse), passed by value so they live in SGPRs.
+template <class MM>
+struct Roots64 {
+    typename MM::tw_t w[32];
+};
+
+// One column pass of the 4-step decomposition (see DESIGN.md "Index maps").
+template <class MM>
+struct ColArgs {
+    const uint32_t *in[2];               // blockIdx.z selects the operand (a / b)
+    uint32_t *out[2];
+    size_t in_stride, out_stride;        // elements between consecutive batch rows
+    uint32_t in_len, out_len;            // valid elements per row: loads beyond in_len read 0,
+                                         // stores beyond out_len are dropped
+    int logM, logS;                      // block size M = N1 * S
+    const typename MM::tw_t *tw;         // [N1][S] 4-step twiddles w_M^(+-i2*k1) (row 0 unused unless scale0)
+    typename MM::tw_t scale0;            // inverse: multiplier of row k1 = 0 (carries L^-1), if use_scale0
+    int use_scale0;
+    int canon;                           // 1: final pass, store canonical residues
+    Roots64<MM> roots;
+};
+
+template <class MM>
+struct RowArgs {
+    const uint32_t *a, *b;               // [rows][4096]; b unused by the single-operand kernels
+    uint32_t *out;
+    const typename MM::tw_t *twA, *twB;          // forward [16][256], [16][16]
+    const typename MM::tw_t *itwA, *itwB;        // inverse
+    Roots64<MM> roots, iroots;
+};
+
+template <class MM>
+struct SmallArgs {
+    const uint32_t *a, *b;
+    uint32_t *out;
+    size_t in_stride, out_stride;
+    uint32_t in_len, out_len;
+    int logL;
+    const typename MM::tw_t *w, *iw;     // w_L^j and w_L^-j, j < L/2
+    typename MM::tw_t scale;             // L^-1 (times R for Montgomery's pointwise product)
+    int mode;                            // 0 multiply, 1 forward (natural out), 2 inverse (natural in)
+};
+
+// One of the four CRT primes: Barrett constants plus the Shoup forms of 1 and 2^32 mod m.
+struct CrtPrime {
+    ModParams mp;
+    Barrett32::tw_t one, two32;
+};
+struct CrtConsts {
+    CrtPrime prime[4];
+    Barrett32::tw_t inv[4][4];           // inv[i][j] = m_i^-1 mod m_j (i < j), Shoup form mod m_j
+    uint64_t p64, nprime64;              // target modulus (odd, < 2^63), -p64^-1 mod 2^64
+    uint64_t mR[4];                      // m_k * 2^64 mod p64
+};
+
+// kind: 0 Montgomery, 1 Barrett; lazy: values kept in [0,2p) (needs 4p <= 2^32)
+void launch_col(int kind, bool lazy, int logN1, bool inverse, bool half_in, const void *args,
+                const ModParams &mp, unsigned cols_per_row, unsigned batch, unsigned nops,
+                hipStream_t s);
+void launch_row_mul(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);
+void launch_row_fwd(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);
+void launch_row_inv(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);
+void launch_small(int kind, bool lazy, const void *args, const ModParams &mp, unsigned batch, hipStream_t s);
+
+// dst[row][perm(i)] = src[row][i] (to_natural) or dst[row][i] = src[row][perm(i)]; perm is the
+// mixed-radix digit reversal defined by the column levels (logs, outermost first) + the row.
+struct PermArgs {
+    const uint32_t *src;
+    uint32_t *dst;
+    int logL;
+    int nlevels;
+    int level_log[8];
+    int to_natural;
+    uint32_t canon_p;                    // != 0: values are in [0, 2p), store canonical residues
+};
+void launch_permute(const PermArgs &pa, unsigned batch, hipStream_t s);
+
+void launch_crt_reduce(const uint64_t *x, uint32_t *out, size_t n, const CrtPrime &c, hipStream_t s);
+void launch_crt_merge(const uint32_t *const res[4], uint64_t *out, size_t n, const CrtConsts &cc,
+                      hipStream_t s);
+
+}  // namespace ntt

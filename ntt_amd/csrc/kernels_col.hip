@@ -1,0 +1,103 @@
+// kernels_col.hip -- column passes of the 4-step (Bailey) decomposition, gfx950.
+//
+// One thread owns one column of a block viewed as an N1 x S matrix (N1 <= 64): it loads the N1
+// points (stride S; across the 64 lanes of a wave every load/store instruction touches 256
+// contiguous bytes), transforms them entirely in VGPRs with SGPR twiddles, applies the 4-step
+// twiddle w_M^(i2*k1) from the HBM table and stores.  No LDS, no barrier.
+//
+// Replaces the large-stride stages (len > 4096) of NTT_iterative, main-montgomery.cc:260-283,
+// which sweep the whole array once per stage; here log2(N1) stages cost one read and one write.
+//
+// Forward: x -> NTT_N1 over i1 -> times w_M^(i2*k1) -> row k1.            (zero padding: loads
+//          beyond in_len return 0; HALF skips the upper half entirely)
+// Inverse: row k1 times w_M^(-i2*k1) [row 0 times scale0] -> inverse NTT_N1 -> row i1; the
+//          outermost inverse pass stores canonical residues and drops indices >= out_len.
+#include "device_ntt.hpp"
+
+namespace ntt {
+
+template <class MM, bool LAZY, int LOGN1, bool INVERSE, bool HALF>
+__global__ void __launch_bounds__(256) col_kernel(const ColArgs<MM> a, const ModParams m)
+{
+    using O = Ops<MM, LAZY>;
+    constexpr int N1 = 1 << LOGN1;
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;          // column id within the row
+    const uint32_t S = 1u << a.logS;
+    const uint32_t i2 = c & (S - 1);
+    const uint32_t base = ((c >> a.logS) << a.logM) + i2;        // blk * M + i2
+    const int op = blockIdx.z;
+    const uint32_t *__restrict__ in = a.in[op] + (size_t)blockIdx.y * a.in_stride;
+    uint32_t *__restrict__ out = a.out[op] + (size_t)blockIdx.y * a.out_stride;
+    const typename MM::tw_t *__restrict__ tw = a.tw + i2;
+
+    uint32_t x[N1];
+#pragma unroll
+    for (int i1 = 0; i1 < N1; ++i1) {
+        if (HALF && i1 >= N1 / 2) {
+            x[i1] = 0;
+        } else {
+            const uint32_t idx = base + ((uint32_t)i1 << a.logS);
+            x[i1] = idx < a.in_len ? in[idx] : 0u;
+        }
+    }
+    if constexpr (INVERSE) {
+        if (a.use_scale0) x[0] = O::mul_tw(x[0], a.scale0, m);
+#pragma unroll
+        for (int k1 = 1; k1 < N1; ++k1) x[k1] = O::mul_tw(x[k1], tw[(size_t)k1 << a.logS], m);
+    }
+    reg_ntt<MM, LAZY, LOGN1, HALF>(x, a.roots, m);
+    if constexpr (!INVERSE) {
+#pragma unroll
+        for (int k1 = 1; k1 < N1; ++k1) x[k1] = O::mul_tw(x[k1], tw[(size_t)k1 << a.logS], m);
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < N1; ++k1) {
+        const uint32_t idx = base + ((uint32_t)k1 << a.logS);
+        if (idx < a.out_len) out[idx] = a.canon ? O::canon(x[k1], m) : x[k1];
+    }
+}
+
+template <class MM, bool LAZY, int LOGN1>
+static void launch_col_t(bool inverse, bool half_in, const ColArgs<MM> &a, const ModParams &mp,
+                         dim3 grid, hipStream_t s)
+{
+    if (inverse)
+        hipLaunchKernelGGL((col_kernel<MM, LAZY, LOGN1, true, false>), grid, dim3(256), 0, s, a, mp);
+    else if (half_in)
+        hipLaunchKernelGGL((col_kernel<MM, LAZY, LOGN1, false, true>), grid, dim3(256), 0, s, a, mp);
+    else
+        hipLaunchKernelGGL((col_kernel<MM, LAZY, LOGN1, false, false>), grid, dim3(256), 0, s, a, mp);
+}
+
+template <class MM, bool LAZY>
+static void launch_col_l(int logN1, bool inverse, bool half_in, const ColArgs<MM> &a,
+                         const ModParams &mp, dim3 grid, hipStream_t s)
+{
+    switch (logN1) {
+    case 1: launch_col_t<MM, LAZY, 1>(inverse, half_in, a, mp, grid, s); break;
+    case 2: launch_col_t<MM, LAZY, 2>(inverse, half_in, a, mp, grid, s); break;
+    case 3: launch_col_t<MM, LAZY, 3>(inverse, half_in, a, mp, grid, s); break;
+    case 4: launch_col_t<MM, LAZY, 4>(inverse, half_in, a, mp, grid, s); break;
+    case 5: launch_col_t<MM, LAZY, 5>(inverse, half_in, a, mp, grid, s); break;
+    case 6: launch_col_t<MM, LAZY, 6>(inverse, half_in, a, mp, grid, s); break;
+    default: break;
+    }
+}
+
+void launch_col(int kind, bool lazy, int logN1, bool inverse, bool half_in, const void *args,
+                const ModParams &mp, unsigned cols_per_row, unsigned batch, unsigned nops,
+                hipStream_t s)
+{
+    dim3 grid(cols_per_row / 256, batch, nops);
+    if (kind == 0) {
+        const auto &a = *static_cast<const ColArgs<Mont32> *>(args);
+        if (lazy) launch_col_l<Mont32, true>(logN1, inverse, half_in, a, mp, grid, s);
+        else launch_col_l<Mont32, false>(logN1, inverse, half_in, a, mp, grid, s);
+    } else {
+        const auto &a = *static_cast<const ColArgs<Barrett32> *>(args);
+        if (lazy) launch_col_l<Barrett32, true>(logN1, inverse, half_in, a, mp, grid, s);
+        else launch_col_l<Barrett32, false>(logN1, inverse, half_in, a, mp, grid, s);
+    }
+}
+
+}  // namespace ntt

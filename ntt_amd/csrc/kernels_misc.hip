@@ -1,0 +1,219 @@
+// kernels_misc.hip -- small-length transforms, order permutation and the CRT kernels, gfx950.
+#include "device_ntt.hpp"
+
+namespace ntt {
+
+// ------------------------------------------------------------------------------------------------
+// small_kernel: L <= 4096.  One workgroup per polynomial pair; the whole product (pad, two forward
+// transforms, pointwise product, inverse transform, scaling) runs out of one 32 KiB LDS tile with
+// radix-2 stages.  This is the plumbing path for the reference's tiny case (nttdata/0.in, n = 4)
+// and for unit-test sizes; the throughput path is kernels_col/kernels_row.
+// Replaces main-montgomery.cc:326-351 for len <= 4096.
+// ------------------------------------------------------------------------------------------------
+template <class MM, bool LAZY>
+__device__ __forceinline__ void lds_dif(uint32_t *x, int logL, const typename MM::tw_t *__restrict__ w,
+                                        const ModParams &m)
+{
+    using O = Ops<MM, LAZY>;
+    const uint32_t L = 1u << logL;
+    for (int s = 0; s < logL; ++s) {
+        const uint32_t half = L >> (s + 1);
+        for (uint32_t idx = threadIdx.x; idx < L / 2; idx += 256) {
+            const uint32_t j = idx & (half - 1);
+            const uint32_t lo = ((idx - j) << 1) + j;
+            const uint32_t u = x[lo], v = x[lo + half];
+            x[lo] = O::add(u, v, m);
+            x[lo + half] = O::mul_tw(O::sub_raw(u, v, m), w[j << s], m);
+        }
+        __syncthreads();
+    }
+}
+
+template <class MM, bool LAZY>
+__device__ __forceinline__ void lds_dit(uint32_t *x, int logL, const typename MM::tw_t *__restrict__ w,
+                                        const ModParams &m)
+{
+    using O = Ops<MM, LAZY>;
+    const uint32_t L = 1u << logL;
+    for (int s = logL - 1; s >= 0; --s) {
+        const uint32_t half = L >> (s + 1);
+        for (uint32_t idx = threadIdx.x; idx < L / 2; idx += 256) {
+            const uint32_t j = idx & (half - 1);
+            const uint32_t lo = ((idx - j) << 1) + j;
+            const uint32_t u = x[lo], v = O::mul_tw(x[lo + half], w[j << s], m);
+            x[lo] = O::add(u, v, m);
+            x[lo + half] = O::sub(u, v, m);
+        }
+        __syncthreads();
+    }
+}
+
+template <class MM, bool LAZY>
+__global__ void __launch_bounds__(256) small_kernel(const SmallArgs<MM> a, const ModParams m)
+{
+    using O = Ops<MM, LAZY>;
+    __shared__ uint32_t A[kRowLen];
+    __shared__ uint32_t B[kRowLen];
+    const uint32_t L = 1u << a.logL;
+    const uint32_t *__restrict__ pa = a.a + (size_t)blockIdx.x * a.in_stride;
+    uint32_t *__restrict__ po = a.out + (size_t)blockIdx.x * a.out_stride;
+    if (a.mode == 0) {
+        const uint32_t *__restrict__ pb = a.b + (size_t)blockIdx.x * a.in_stride;
+        for (uint32_t i = threadIdx.x; i < L; i += 256) {
+            A[i] = i < a.in_len ? pa[i] : 0u;
+            B[i] = i < a.in_len ? pb[i] : 0u;
+        }
+        __syncthreads();
+        lds_dif<MM, LAZY>(A, a.logL, a.w, m);
+        lds_dif<MM, LAZY>(B, a.logL, a.w, m);
+        for (uint32_t i = threadIdx.x; i < L; i += 256) A[i] = O::mul(A[i], B[i], m);
+        __syncthreads();
+        lds_dit<MM, LAZY>(A, a.logL, a.iw, m);
+        for (uint32_t i = threadIdx.x; i < L && i < a.out_len; i += 256)
+            po[i] = csub(MM::mul_tw(A[i], a.scale, m), m.p);
+    } else if (a.mode == 1) {
+        for (uint32_t i = threadIdx.x; i < L; i += 256) A[i] = pa[i];
+        __syncthreads();
+        lds_dif<MM, LAZY>(A, a.logL, a.w, m);
+        for (uint32_t i = threadIdx.x; i < L; i += 256)
+            po[__brev(i) >> (32 - a.logL)] = O::canon(A[i], m);
+    } else {
+        for (uint32_t i = threadIdx.x; i < L; i += 256) A[__brev(i) >> (32 - a.logL)] = pa[i];
+        __syncthreads();
+        lds_dit<MM, LAZY>(A, a.logL, a.iw, m);
+        for (uint32_t i = threadIdx.x; i < L; i += 256) po[i] = csub(MM::mul_tw(A[i], a.scale, m), m.p);
+    }
+}
+
+void launch_small(int kind, bool lazy, const void *args, const ModParams &mp, unsigned batch, hipStream_t s)
+{
+    if (kind == 0) {
+        const auto &a = *static_cast<const SmallArgs<Mont32> *>(args);
+        if (lazy) hipLaunchKernelGGL((small_kernel<Mont32, true>), dim3(batch), dim3(256), 0, s, a, mp);
+        else hipLaunchKernelGGL((small_kernel<Mont32, false>), dim3(batch), dim3(256), 0, s, a, mp);
+    } else {
+        const auto &a = *static_cast<const SmallArgs<Barrett32> *>(args);
+        if (lazy) hipLaunchKernelGGL((small_kernel<Barrett32, true>), dim3(batch), dim3(256), 0, s, a, mp);
+        else hipLaunchKernelGGL((small_kernel<Barrett32, false>), dim3(batch), dim3(256), 0, s, a, mp);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// permute_kernel: converts between natural order and the engine's digit-reversed spectrum order
+// for the public ntt_forward / ntt_inverse (NTT_iterative is natural-in / natural-out,
+// main-montgomery.cc:255-295).  The multiply path never runs it.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) permute_kernel(const PermArgs pa)
+{
+    const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
+    const size_t row = (size_t)blockIdx.y << pa.logL;
+    int shift = pa.logL, acc = 0;
+    uint32_t k = 0;
+    for (int d = 0; d < pa.nlevels; ++d) {
+        const int w = pa.level_log[d];
+        shift -= w;
+        k |= ((pos >> shift) & ((1u << w) - 1)) << acc;
+        acc += w;
+    }
+    if (pa.to_natural) {
+        uint32_t v = pa.src[row + pos];
+        if (pa.canon_p) v = csub(v, pa.canon_p);
+        pa.dst[row + k] = v;
+    } else {
+        pa.dst[row + pos] = pa.src[row + k];
+    }
+}
+
+void launch_permute(const PermArgs &pa, unsigned batch, hipStream_t s)
+{
+    hipLaunchKernelGGL(permute_kernel, dim3((1u << pa.logL) / 256, batch), dim3(256), 0, s, pa);
+}
+
+// ------------------------------------------------------------------------------------------------
+// CRT kernels.  Replace CRT_parallel's implicit input reduction (main-openmp.cc:426-427) and
+// CRT_combine_parallel (main-openmp.cc:468-485).  The reference sums r_k * inv_k * (M/m_k) mod M
+// with __uint128_t `%` (software division); on the GPU the same canonical value is obtained by
+// Garner's mixed-radix form with 32-bit Shoup multiplications followed by a Horner evaluation
+// mod p64 with 64-bit Montgomery multiplications -- no 128-bit division, no MFMA.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t red32(uint32_t x, const CrtPrime &c)    // x mod m, any u32 x
+{
+    return csub(Barrett32::mul_tw(x, c.one, c.mp), c.mp.p);
+}
+
+__global__ void __launch_bounds__(256) crt_reduce_kernel(const uint64_t *__restrict__ x,
+                                                         uint32_t *__restrict__ out, size_t n,
+                                                         const CrtPrime c)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t v = x[i];
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    // v = hi * 2^32 + lo
+    const uint32_t h = csub(Barrett32::mul_tw(hi, c.two32, c.mp), c.mp.p);
+    const uint32_t l = red32(lo, c);
+    out[i] = csub(h + l, c.mp.p);
+}
+
+void launch_crt_reduce(const uint64_t *x, uint32_t *out, size_t n, const CrtPrime &c, hipStream_t s)
+{
+    hipLaunchKernelGGL(crt_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out, n, c);
+}
+
+// (acc - v) * inv mod m_j, acc in [0, m_j), v any u32
+__device__ __forceinline__ uint32_t garner_step(uint32_t acc, uint32_t v, Barrett32::tw_t inv,
+                                                const CrtPrime &c)
+{
+    const uint32_t d = acc - red32(v, c) + c.mp.p;                  // (0, 2 m_j)
+    return csub(Barrett32::mul_tw(d, inv, c.mp), c.mp.p);
+}
+
+__device__ __forceinline__ uint64_t mont64_mul(uint64_t a, uint64_t b, const CrtConsts &cc)
+{
+    // REDC(a*b) with R = 2^64; a*b < p64 * 2^64, p64 < 2^63
+    const uint64_t lo = a * b, hi = __umul64hi(a, b);
+    const uint64_t q = lo * cc.nprime64;
+    uint64_t t = hi + __umul64hi(q, cc.p64) + (lo != 0 ? 1u : 0u);   // low words cancel to 0 or 2^64
+    return t >= cc.p64 ? t - cc.p64 : t;
+}
+
+__global__ void __launch_bounds__(256) crt_merge_kernel(const uint32_t *__restrict__ r0,
+                                                        const uint32_t *__restrict__ r1,
+                                                        const uint32_t *__restrict__ r2,
+                                                        const uint32_t *__restrict__ r3,
+                                                        uint64_t *__restrict__ out, size_t n,
+                                                        const CrtConsts cc)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    // Garner: x = v0 + m0 * (v1 + m1 * (v2 + m2 * v3)), v_j in [0, m_j)
+    const uint32_t v0 = r0[i];
+    const uint32_t v1 = garner_step(r1[i], v0, cc.inv[0][1], cc.prime[1]);
+    uint32_t v2 = garner_step(r2[i], v0, cc.inv[0][2], cc.prime[2]);
+    v2 = garner_step(v2, v1, cc.inv[1][2], cc.prime[2]);
+    uint32_t v3 = garner_step(r3[i], v0, cc.inv[0][3], cc.prime[3]);
+    v3 = garner_step(v3, v1, cc.inv[1][3], cc.prime[3]);
+    v3 = garner_step(v3, v2, cc.inv[2][3], cc.prime[3]);
+    // Horner mod p64; plain value times Montgomery-form constant = plain value
+    const uint64_t p = cc.p64;
+    auto addmod = [p](uint64_t x, uint32_t v) {
+        uint64_t vv = v;
+        if (vv >= p) vv %= p;                                       // only when p64 < 2^31
+        const uint64_t s = x + vv;
+        return s >= p ? s - p : s;
+    };
+    uint64_t acc = addmod(0, v3);
+    acc = addmod(mont64_mul(acc, cc.mR[2], cc), v2);
+    acc = addmod(mont64_mul(acc, cc.mR[1], cc), v1);
+    acc = addmod(mont64_mul(acc, cc.mR[0], cc), v0);
+    out[i] = acc;
+}
+
+void launch_crt_merge(const uint32_t *const res[4], uint64_t *out, size_t n, const CrtConsts &cc,
+                      hipStream_t s)
+{
+    hipLaunchKernelGGL(crt_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, res[0],
+                       res[1], res[2], res[3], out, n, cc);
+}
+
+}  // namespace ntt

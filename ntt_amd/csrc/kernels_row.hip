@@ -1,0 +1,179 @@
+// kernels_row.hip -- LDS-staged 4096-point row transforms and the fused multiply kernel, gfx950.
+//
+// One workgroup (256 threads = 4 waves, 16 points per thread) owns one contiguous 4096-point
+// row.  A row transform is three radix-16 register passes (4096 = 16*16*16) with two exchanges
+// through a 17 KiB LDS tile; both exchange layouts are padded so that every ds_read_b32 /
+// ds_write_b32 is bank-conflict free:
+//     exchange 1: P1(i) = i + 16*(i >> 8)   written  k*256 + t,        read  b*256 + j*16 + i
+//     exchange 2: P2(i) = i + (i >> 4)      written  b*256 + k*16 + i, read  t*16 + j
+// The forward transform leaves the spectrum in digit-reversed order (position k1*256+k2*16+k3
+// holds natural index k1 + 16*k2 + 256*k3); the inverse consumes exactly that order, so no
+// bit-reversal pass (main-montgomery.cc:238-253) exists anywhere.
+//
+// row_mul_kernel fuses: forward(a row), forward(b row), pointwise product
+// (main-montgomery.cc:341-344) and the inverse row transform -- the 12 small-stride stages of
+// three NTT_iterative calls plus the pointwise loop in one read of a, b and one write.
+#include "device_ntt.hpp"
+
+namespace ntt {
+
+constexpr int kLdsWords = kRowLen + kRowLen / 16;      // 4352 dwords = 17 KiB
+
+__device__ __forceinline__ uint32_t P1(uint32_t i) { return i + ((i >> 8) << 4); }
+__device__ __forceinline__ uint32_t P2(uint32_t i) { return i + (i >> 4); }
+
+// x[j] = row[t + 256*j] on entry; on exit x[k] = spectrum at position 16*t + k.
+template <class MM, bool LAZY>
+__device__ __forceinline__ void row_forward(uint32_t (&x)[16], uint32_t *lds, const uint32_t t,
+                                            const RowArgs<MM> &a, const ModParams &m)
+{
+    using O = Ops<MM, LAZY>;
+    reg_ntt<MM, LAZY, 4, false>(x, a.roots, m);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], a.twA[k * 256 + t], m);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[P1(k * 256 + t)] = x[k];
+    __syncthreads();
+    const uint32_t b = t >> 4, i = t & 15;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = lds[P1(b * 256 + j * 16 + i)];
+    __syncthreads();
+    reg_ntt<MM, LAZY, 4, false>(x, a.roots, m);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], a.twB[k * 16 + i], m);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[P2(b * 256 + k * 16 + i)] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = lds[P2(t * 16 + j)];
+    __syncthreads();
+    reg_ntt<MM, LAZY, 4, false>(x, a.roots, m);
+}
+
+// x[k] = spectrum at position 16*t + k on entry; on exit x[j] = row[t + 256*j] (unscaled).
+template <class MM, bool LAZY>
+__device__ __forceinline__ void row_inverse(uint32_t (&x)[16], uint32_t *lds, const uint32_t t,
+                                            const RowArgs<MM> &a, const ModParams &m)
+{
+    using O = Ops<MM, LAZY>;
+    reg_ntt<MM, LAZY, 4, false>(x, a.iroots, m);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) lds[P2(t * 16 + j)] = x[j];
+    __syncthreads();
+    const uint32_t b = t >> 4, i = t & 15;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[P2(b * 256 + k * 16 + i)];
+    __syncthreads();
+#pragma unroll
+    for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], a.itwB[k * 16 + i], m);
+    reg_ntt<MM, LAZY, 4, false>(x, a.iroots, m);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) lds[P1(b * 256 + j * 16 + i)] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[P1(k * 256 + t)];
+    __syncthreads();
+#pragma unroll
+    for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], a.itwA[k * 256 + t], m);
+    reg_ntt<MM, LAZY, 4, false>(x, a.iroots, m);
+}
+
+template <class MM, bool LAZY>
+__global__ void __launch_bounds__(256) row_mul_kernel(const RowArgs<MM> a, const ModParams m)
+{
+    using O = Ops<MM, LAZY>;
+    __shared__ uint32_t lds[kLdsWords];
+    const uint32_t t = threadIdx.x;
+    const size_t row = (size_t)blockIdx.x * kRowLen;
+    const uint32_t *__restrict__ pa = a.a + row;
+    const uint32_t *__restrict__ pb = a.b + row;
+    uint32_t xa[16], xb[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xa[j] = pa[t + 256 * j];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xb[j] = pb[t + 256 * j];
+    row_forward<MM, LAZY>(xa, lds, t, a, m);
+    row_forward<MM, LAZY>(xb, lds, t, a, m);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) xa[k] = O::mul(xa[k], xb[k], m);
+    row_inverse<MM, LAZY>(xa, lds, t, a, m);
+    uint32_t *__restrict__ po = a.out + row;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) po[t + 256 * j] = xa[j];
+}
+
+// Forward only: natural row in, digit-reversed spectrum out (position 16*t + k).
+template <class MM, bool LAZY>
+__global__ void __launch_bounds__(256) row_fwd_kernel(const RowArgs<MM> a, const ModParams m)
+{
+    __shared__ uint32_t lds[kLdsWords];
+    const uint32_t t = threadIdx.x;
+    const size_t row = (size_t)blockIdx.x * kRowLen;
+    const uint32_t *__restrict__ pa = a.a + row;
+    uint32_t x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = pa[t + 256 * j];
+    row_forward<MM, LAZY>(x, lds, t, a, m);
+    uint4 *__restrict__ po = reinterpret_cast<uint4 *>(a.out + row + 16 * t);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) po[q] = make_uint4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+}
+
+// Inverse only: digit-reversed spectrum in, natural row out (unscaled; the column pass or the
+// caller's scale twiddle finishes it).
+template <class MM, bool LAZY>
+__global__ void __launch_bounds__(256) row_inv_kernel(const RowArgs<MM> a, const ModParams m)
+{
+    __shared__ uint32_t lds[kLdsWords];
+    const uint32_t t = threadIdx.x;
+    const size_t row = (size_t)blockIdx.x * kRowLen;
+    const uint4 *__restrict__ pa = reinterpret_cast<const uint4 *>(a.a + row + 16 * t);
+    uint32_t x[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 v = pa[q];
+        x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+    }
+    row_inverse<MM, LAZY>(x, lds, t, a, m);
+    uint32_t *__restrict__ po = a.out + row;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) po[t + 256 * j] = x[j];
+}
+
+template <int WHICH, class MM, bool LAZY>
+static void launch_row_t(const RowArgs<MM> &a, const ModParams &mp, unsigned rows, hipStream_t s)
+{
+    if (WHICH == 0) hipLaunchKernelGGL((row_mul_kernel<MM, LAZY>), dim3(rows), dim3(256), 0, s, a, mp);
+    if (WHICH == 1) hipLaunchKernelGGL((row_fwd_kernel<MM, LAZY>), dim3(rows), dim3(256), 0, s, a, mp);
+    if (WHICH == 2) hipLaunchKernelGGL((row_inv_kernel<MM, LAZY>), dim3(rows), dim3(256), 0, s, a, mp);
+}
+
+template <int WHICH>
+static void launch_row_any(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows,
+                           hipStream_t s)
+{
+    if (kind == 0) {
+        const auto &a = *static_cast<const RowArgs<Mont32> *>(args);
+        if (lazy) launch_row_t<WHICH, Mont32, true>(a, mp, rows, s);
+        else launch_row_t<WHICH, Mont32, false>(a, mp, rows, s);
+    } else {
+        const auto &a = *static_cast<const RowArgs<Barrett32> *>(args);
+        if (lazy) launch_row_t<WHICH, Barrett32, true>(a, mp, rows, s);
+        else launch_row_t<WHICH, Barrett32, false>(a, mp, rows, s);
+    }
+}
+
+void launch_row_mul(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s)
+{
+    launch_row_any<0>(kind, lazy, args, mp, rows, s);
+}
+void launch_row_fwd(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s)
+{
+    launch_row_any<1>(kind, lazy, args, mp, rows, s);
+}
+void launch_row_inv(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s)
+{
+    launch_row_any<2>(kind, lazy, args, mp, rows, s);
+}
+
+}  // namespace ntt

@@ -1,0 +1,111 @@
+// ntt_cli.cpp -- the reference harness loop on top of libntt_amd.so's C ABI.
+//
+// Mirrors main() of main-montgomery.cc:298-362 / main-openmp.cc:632-727: for each case id in
+// [test_begin, test_end] read "<data>/<id>.in", multiply (50 epochs, averaged), check against
+// "<data>/<id>.out", print the verdict and the "average latency for n = .. p = .. : .. (us)" line
+// (value in milliseconds, as the reference prints it), write "<out>/<id>.out".
+// Differences on purpose: the data/out directories and the case range come from the command
+// line (the reference hard-codes "/nttdata/" and 0..4), a missing case is reported and skipped
+// instead of producing a spurious verdict, and the exit status is non-zero on any mismatch.
+//
+//   ntt_cli [--data DIR] [--out DIR] [--begin N] [--end N] [--epochs N] [--barrett]
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ntt_amd.h"
+
+int main(int argc, char **argv)
+{
+    std::string data = "./nttdata", out = "./files";
+    int begin = 0, end = 4, epochs = 50, kind = NTT_MODMUL_MONTGOMERY;
+    for (int i = 1; i < argc; ++i) {
+        auto need = [&](const char *flag) -> const char * {
+            if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", flag); std::exit(2); }
+            return argv[++i];
+        };
+        if (!std::strcmp(argv[i], "--data")) data = need("--data");
+        else if (!std::strcmp(argv[i], "--out")) out = need("--out");
+        else if (!std::strcmp(argv[i], "--begin")) begin = std::atoi(need("--begin"));
+        else if (!std::strcmp(argv[i], "--end")) end = std::atoi(need("--end"));
+        else if (!std::strcmp(argv[i], "--epochs")) epochs = std::atoi(need("--epochs"));
+        else if (!std::strcmp(argv[i], "--barrett")) kind = NTT_MODMUL_BARRETT;
+        else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
+    }
+    if (epochs < 1) epochs = 1;
+    ntt_ctx *ctx = nullptr;
+    int dev = 0;
+    if (ntt_ctx_create(&dev, 1, &ctx) != NTT_OK) {
+        std::fprintf(stderr, "ntt_ctx_create: %s\n", ntt_last_error());
+        return 1;
+    }
+    const size_t cap = 1u << 22;
+    std::vector<uint64_t> a(cap), b(cap), ab;
+    int bad = 0;
+    for (int id = begin; id <= end; ++id) {
+        int n = 0;
+        uint64_t p = 0;
+        int rc = ntt_read_case(data.c_str(), id, a.data(), b.data(), cap, &n, &p);
+        if (rc != NTT_OK) {
+            std::fprintf(stderr, "case %d skipped: %s\n", id, ntt_last_error());
+            continue;
+        }
+        ab.assign((size_t)2 * n - 1, 0);
+        double total_ms = 0;
+        if (p < (1ULL << 31)) {
+            ntt_plan *plan = nullptr;
+            if (ntt_plan_create(ctx, (uint32_t)p, n, 1, kind, &plan) != NTT_OK) {
+                std::fprintf(stderr, "case %d: %s\n", id, ntt_last_error());
+                ++bad;
+                continue;
+            }
+            std::vector<uint32_t> a32(n), b32(n), ab32((size_t)2 * n - 1);
+            for (int i = 0; i < n; ++i) { a32[i] = (uint32_t)a[i]; b32[i] = (uint32_t)b[i]; }
+            uint32_t *da, *db, *dab;
+            (void)hipMalloc(&da, (size_t)n * 4);
+            (void)hipMalloc(&db, (size_t)n * 4);
+            (void)(void)hipMalloc(&dab, ab32.size() * 4);
+            (void)hipMemcpy(da, a32.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+            (void)hipMemcpy(db, b32.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+            for (int e = 0; e < epochs + 1; ++e) {      // epoch 0 warms up (module load), untimed
+                auto t0 = std::chrono::high_resolution_clock::now();
+                rc = ntt_poly_multiply_batched(plan, da, db, dab, ab32.size(), 1);
+                if (rc == NTT_OK) rc = ntt_ctx_synchronize(ctx);
+                auto t1 = std::chrono::high_resolution_clock::now();
+                if (rc != NTT_OK) break;
+                if (e > 0) total_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+            }
+            (void)hipMemcpy(ab32.data(), dab, ab32.size() * 4, hipMemcpyDeviceToHost);
+            (void)hipFree(da); (void)hipFree(db); (void)hipFree(dab);
+            ntt_plan_destroy(plan);
+            for (size_t i = 0; i < ab32.size(); ++i) ab[i] = ab32[i];
+        } else {
+            for (int e = 0; e < epochs + 1; ++e) {
+                auto t0 = std::chrono::high_resolution_clock::now();
+                rc = ntt_crt_multiply(ctx, a.data(), b.data(), ab.data(), n, p);
+                auto t1 = std::chrono::high_resolution_clock::now();
+                if (rc != NTT_OK) break;
+                if (e > 0) total_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+            }
+        }
+        if (rc != NTT_OK) {
+            std::fprintf(stderr, "case %d: %s\n", id, ntt_last_error());
+            ++bad;
+            continue;
+        }
+        rc = ntt_check_case(data.c_str(), id, ab.data(), n);
+        if (rc == NTT_ERR_MISMATCH) ++bad;
+        else if (rc != NTT_OK) std::fprintf(stderr, "case %d not checked: %s\n", id, ntt_last_error());
+        std::printf("average latency for n = %d p = %llu : %g (us) \n", n, (unsigned long long)p,
+                    total_ms / epochs);
+        if (ntt_write_case(out.c_str(), id, ab.data(), n) != NTT_OK)
+            std::fprintf(stderr, "case %d not written: %s\n", id, ntt_last_error());
+    }
+    ntt_ctx_destroy(ctx);
+    return bad ? 1 : 0;
+}

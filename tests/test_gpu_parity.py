@@ -1,0 +1,292 @@
+"""GPU parity tests: the HIP path (through the C ABI of libntt_amd.so) against the CPU oracle,
+the reference's shipped nttdata fixtures and the vectors produced by the compiled reference.
+Bit-exact (integer arithmetic): every comparison is array equality.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+PRIMES = (7340033, 104857601, 469762049, 998244353)
+KINDS = {"mont": 0, "barrett": 1}
+
+
+@pytest.fixture(scope="module")
+def nt():
+    import ntt_amd
+    return ntt_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(nt):
+    c = nt.Context(0)
+    yield c
+    c.close()
+
+
+def rand_poly(rng, n, p, batch=None):
+    shape = (n,) if batch is None else (batch, n)
+    return rng.integers(0, p, size=shape, dtype=np.int64).astype(np.uint32)
+
+
+# ---- the reference's shipped cases (golden vectors that pin the path) -----------------
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_nttdata_legacy_entry_point(nt, nttdata, cid):
+    n, p, a, b, ab = nttdata[cid]
+    got = nt.poly_multiply(a.astype(np.int32), b.astype(np.int32), p)
+    assert np.array_equal(got.astype(np.uint32), ab)
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+@pytest.mark.parametrize("kind", ["mont", "barrett"])
+def test_nttdata_plan(nt, ctx, nttdata, cid, kind):
+    n, p, a, b, ab = nttdata[cid]
+    plan = ctx.plan(p, n, 1, KINDS[kind])
+    got = plan.multiply(a.reshape(1, n), b.reshape(1, n))
+    assert np.array_equal(got[0], ab)
+    plan.close()
+
+
+def test_legacy_entry_leaves_tail_untouched(nt, nttdata):
+    # ownership rule: entries >= 2n-1 of ab are not written
+    import ctypes as C
+    n, p, a, b, ab = nttdata[0]
+    buf = np.full(300000, -7, dtype=np.int32)
+    a32, b32 = a.astype(np.int32), b.astype(np.int32)
+    nt._lib.poly_multiply(a32.ctypes.data, b32.ctypes.data, buf.ctypes.data, n, p)
+    assert np.array_equal(buf[:2 * n - 1].astype(np.uint32), ab)
+    assert np.all(buf[2 * n - 1:] == -7)
+
+
+# ---- vectors made by the compiled reference (tests/golden/make_golden.py) --------------------------
+@pytest.mark.parametrize("kind", ["mont", "barrett"])
+def test_reference_polymul_vectors(ctx, ref_polymul_vectors, kind):
+    v = ref_polymul_vectors
+    for k in [k for k in v.files if k.startswith("ab_")]:
+        _, p, n = k.split("_")
+        p, n = int(p), int(n)
+        plan = ctx.plan(p, n, 1, KINDS[kind])
+        got = plan.multiply(v[f"a_{p}_{n}"].reshape(1, n), v[f"b_{p}_{n}"].reshape(1, n))
+        assert np.array_equal(got[0], v[k]), (k, kind)
+        plan.close()
+
+
+@pytest.mark.parametrize("kind", ["mont", "barrett"])
+def test_reference_ntt_vectors(ctx, ref_ntt_vectors, kind):
+    v = ref_ntt_vectors
+    for k in [k for k in v.files if k.startswith("in_")]:
+        _, p, L = k.split("_")
+        p, L = int(p), int(L)
+        plan = ctx.plan(p, L // 2, 1, KINDS[kind])
+        assert plan.length == L
+        x = v[k].copy()
+        assert np.array_equal(plan.forward(x.copy()), v[f"fwd_{p}_{L}"]), (k, kind)
+        assert np.array_equal(plan.inverse(x.copy()), v[f"inv_{p}_{L}"]), (k, kind)
+        plan.close()
+
+
+# ---- seeded synthetic inputs against the oracle, all code paths ------------------------------------
+SIZES = [1, 2, 3, 7, 100, 1000, 2048, 2049, 4096, 5000, 40000, 65536, 100000, 131072]
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("kind", ["mont", "barrett"])
+def test_multiply_vs_oracle(ctx, n, kind):
+    rng = np.random.default_rng(1000 + n)
+    for p in (998244353, 469762049, 1224736769, 7340033):    # lazy, lazy, strict (>2^30), small
+        a, b = rand_poly(rng, n, p), rand_poly(rng, n, p)
+        a[0] = p - 1
+        b[-1] = p - 1
+        plan = ctx.plan(p, n, 1, KINDS[kind])
+        got = plan.multiply(a.reshape(1, n), b.reshape(1, n))[0]
+        want = orc.poly_multiply(a, b, p, kind=kind)
+        assert np.array_equal(got, want), (n, p, kind)
+        plan.close()
+
+
+def test_multi_level_columns(ctx):
+    # L = 2^19 and 2^20: two column levels in front of the 4096-point rows
+    rng = np.random.default_rng(5)
+    for n, p in ((1 << 18, 998244353), (300000, 469762049), (1 << 19, 7340033)):
+        a, b = rand_poly(rng, n, p), rand_poly(rng, n, p)
+        plan = ctx.plan(p, n, 1, 0)
+        got = plan.multiply(a.reshape(1, n), b.reshape(1, n))[0]
+        assert np.array_equal(got, orc.poly_multiply(a, b, p, kind="barrett")), (n, p)
+        plan.close()
+
+
+def test_edge_values(ctx):
+    p = 998244353
+    for n in (4, 4096, 8192):
+        plan = ctx.plan(p, n, 1, 0)
+        for a, b in ((np.zeros(n), np.zeros(n)), (np.full(n, p - 1), np.full(n, p - 1)),
+                     (np.ones(n), np.full(n, p - 1)), (np.eye(1, n, n - 1)[0], np.eye(1, n, n - 1)[0])):
+            a, b = a.astype(np.uint32), b.astype(np.uint32)
+            got = plan.multiply(a.reshape(1, n), b.reshape(1, n))[0]
+            assert np.array_equal(got, orc.poly_multiply(a, b, p)), n
+        plan.close()
+
+
+def test_forced_strict_path_small_prime(nt, ctx):
+    # the [0,p) (non-lazy) kernels are normally used only for p >= 2^30: force them for a small prime
+    os.environ["NTT_AMD_FORCE_STRICT"] = "1"
+    try:
+        rng = np.random.default_rng(9)
+        for n in (1000, 10000):
+            for kind in ("mont", "barrett"):
+                p = 998244353
+                a, b = rand_poly(rng, n, p), rand_poly(rng, n, p)
+                plan = ctx.plan(p, n, 1, KINDS[kind])
+                assert np.array_equal(plan.multiply(a.reshape(1, n), b.reshape(1, n))[0],
+                                      orc.poly_multiply(a, b, p))
+                plan.close()
+    finally:
+        del os.environ["NTT_AMD_FORCE_STRICT"]
+
+
+@pytest.mark.parametrize("kind", ["mont", "barrett"])
+def test_forward_inverse_vs_oracle(ctx, kind):
+    rng = np.random.default_rng(11)
+    for p, L in ((998244353, 8192), (469762049, 1 << 18), (1224736769, 1 << 14), (7340033, 1 << 20),
+                 (998244353, 64), (998244353, 2)):
+        batch = 3 if L <= (1 << 14) else 1
+        x = rand_poly(rng, L, p, batch)
+        plan = ctx.plan(p, L // 2, batch, KINDS[kind])
+        f = plan.forward(x.copy(), batch)
+        for r in range(batch):
+            assert np.array_equal(f[r], orc.ntt(x[r], p)), (p, L, r)
+        i = plan.inverse(x.copy(), batch)
+        for r in range(batch):
+            assert np.array_equal(i[r], orc.ntt(x[r], p, inverse=True)), (p, L, r)
+        assert np.array_equal(plan.inverse(f, batch), x)
+        plan.close()
+
+
+# ---- batched, device-resident, strided output ------------------------------------------------------
+def test_batched_device_resident(ctx):
+    import torch
+    rng = np.random.default_rng(21)
+    for n, batch, p in ((131072, 5, 998244353), (65536, 9, 469762049), (1000, 33, 998244353)):
+        a, b = rand_poly(rng, n, p, batch), rand_poly(rng, n, p, batch)
+        ta = torch.from_numpy(a.view(np.int32)).cuda()
+        tb = torch.from_numpy(b.view(np.int32)).cuda()
+        stride = 2 * n
+        tab = torch.full((batch, stride), -1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        plan = ctx.plan(p, n, batch, 0)
+        plan.multiply(ta, tb, out=tab, batch=batch, out_stride=stride)
+        ctx.synchronize()
+        got = tab.cpu().numpy().view(np.uint32)
+        for r in range(batch):
+            assert np.array_equal(got[r, :2 * n - 1], orc.poly_multiply(a[r], b[r], p)), (n, r)
+        assert np.all(got[:, 2 * n - 1] == 0xFFFFFFFF)          # pad column untouched
+        # inputs are not modified
+        assert np.array_equal(ta.cpu().numpy().view(np.uint32), a)
+        plan.close()
+
+
+def test_chunking_is_transparent(nt, ctx):
+    # the work buffers hold `chunk` products; results must not depend on the chunk size
+    rng = np.random.default_rng(22)
+    n, batch, p = 8192, 7, 998244353
+    a, b = rand_poly(rng, n, p, batch), rand_poly(rng, n, p, batch)
+    outs = []
+    for chunk in ("1", "3", "7"):
+        os.environ["NTT_AMD_CHUNK"] = chunk
+        plan = ctx.plan(p, n, batch, 0)
+        outs.append(plan.multiply(a, b))
+        plan.close()
+    del os.environ["NTT_AMD_CHUNK"]
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert np.array_equal(outs[0][6], orc.poly_multiply(a[6], b[6], p))
+
+
+# ---- size-independent properties at the benchmark size ---------------------------------------------
+def test_full_size_properties(ctx):
+    """n = 2^17, p = 998244353, batch 64 (BASELINE configs[1] shape): checks that need no oracle run
+    per row: multiplying by the constant 1 is the identity, by x^k is a shift, the product commutes,
+    and the coefficient sum equals the product of the coefficient sums (evaluation at x = 1)."""
+    import torch
+    n, batch, p = 131072, 64, 998244353
+    a = (orc.splitmix64_np(0x20250711, batch * n) % np.uint64(p)).astype(np.uint32).reshape(batch, n)
+    b = (orc.splitmix64_np(0x20250711 + 77, batch * n) % np.uint64(p)).astype(np.uint32).reshape(batch, n)
+    plan = ctx.plan(p, n, batch, 0)
+    one = np.zeros((batch, n), dtype=np.uint32)
+    one[:, 0] = 1
+    got = plan.multiply(a, one)
+    assert np.array_equal(got[:, :n], a) and not got[:, n:].any()
+    shift = np.zeros((batch, n), dtype=np.uint32)
+    shift[:, 12345] = 1
+    got = plan.multiply(a, shift)
+    assert np.array_equal(got[:, 12345:12345 + n], a) and not got[:, :12345].any()
+    ab, ba = plan.multiply(a, b), plan.multiply(b, a)
+    assert np.array_equal(ab, ba)
+    sa = a.astype(np.uint64).sum(axis=1) % p
+    sb = b.astype(np.uint64).sum(axis=1) % p
+    sab = ab.astype(np.uint64).sum(axis=1) % p
+    assert np.array_equal(sab, sa * sb % p)
+    # and two rows against the oracle
+    for r in (0, batch - 1):
+        assert np.array_equal(ab[r], orc.poly_multiply(a[r], b[r], p))
+    plan.close()
+
+
+# ---- large modulus through the 4-prime CRT -----------------------------------------------------------
+def test_crt_golden(ctx, crt_vectors):
+    v = crt_vectors
+    p64 = int(v["p64"])
+    for n in (256, 1000):
+        got = ctx.crt_multiply(v[f"a_{n}"], v[f"b_{n}"], p64)
+        assert np.array_equal(got, v[f"ab_{n}"]), n
+
+
+def test_crt_vs_oracle_large(ctx):
+    p64 = 1337006139375617
+    rng = np.random.default_rng(33)
+    for n in (5, 5000, 131072):
+        a = rng.integers(0, p64, size=n, dtype=np.uint64)
+        b = rng.integers(0, p64, size=n, dtype=np.uint64)
+        a[0] = p64 - 1
+        b[0] = p64 - 1
+        want, _ = orc.poly_multiply_crt(a, b, p64, threads=8)
+        assert np.array_equal(ctx.crt_multiply(a, b, p64), want), n
+    # the older modulus of the reference comments (main-montgomery.cc:302)
+    p64 = 263882790666241
+    a = rng.integers(0, p64, size=3000, dtype=np.uint64)
+    b = rng.integers(0, p64, size=3000, dtype=np.uint64)
+    want, _ = orc.poly_multiply_crt(a, b, p64, threads=4)
+    assert np.array_equal(ctx.crt_multiply(a, b, p64), want)
+
+
+# ---- error behaviour -----------------------------------------------------------------------------------
+def test_errors(nt, ctx):
+    with pytest.raises(nt.NttError) as e:
+        ctx.plan(998244353, 1 << 23, 1)          # L = 2^24 > 2-adicity 23
+    assert e.value.code == nt.ERR_UNSUPPORTED
+    with pytest.raises(nt.NttError):
+        ctx.plan(998244351, 16, 1)               # not prime
+    with pytest.raises(nt.NttError):
+        ctx.plan(998244353, 0, 1)
+    with pytest.raises(nt.NttError):
+        ctx.crt_multiply(np.zeros(4, np.uint64), np.zeros(4, np.uint64), 1 << 61)   # even / too big
+    plan = ctx.plan(998244353, 16, 1)
+    with pytest.raises(nt.NttError):
+        plan.multiply(np.zeros((1, 16), np.uint32), np.zeros((1, 16), np.uint32), out_stride=10)
+    plan.close()
+
+
+def test_kernel_timing(ctx):
+    n, p = 65536, 998244353
+    a = np.ones((2, n), dtype=np.uint32)
+    plan = ctx.plan(p, n, 2, 0)
+    ctx.enable_kernel_timing(True)
+    plan.multiply(a, a)
+    t = ctx.kernel_times()
+    ctx.enable_kernel_timing(False)
+    assert t["col_fwd"][1] == 1 and t["row_mul"][1] == 1 and t["col_inv"][1] == 1
+    assert t["row_mul"][0] > 0
+    plan.close()
