@@ -68,24 +68,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-
     import torch                      # device memory, streams and torch.distributed: plumbing
     import ntt_amd                    # the product: HIP kernels behind the C ABI
+    from ntt_amd import shard
 
+    rank, world, local_rank = shard.env_rank_world()
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+    group = shard.Group("nccl", device=torch.device("cuda", local_rank))     # RCCL when world > 1
 
     B, n, p = args.batch, args.n, args.p
     stride = 2 * n
-    seed = 0x20250711 + rank * B          # every rank multiplies different polynomials
+    seed = shard.rank_seed(0x20250711, rank, B)      # every rank multiplies different polynomials
     ha = splitmix_fill(seed, B, n, p)
     hb = splitmix_fill(seed + (1 << 20), B, n, p)
     da = torch.from_numpy(ha.view(np.int32)).cuda()
@@ -104,9 +97,7 @@ def main():
         ctx.synchronize()
         torch.cuda.synchronize()
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    barrier = group.barrier
 
     for _ in range(args.warmup):
         step()
@@ -133,10 +124,7 @@ def main():
     ktimes = ctx.kernel_times()
     ctx.enable_kernel_timing(False)
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = group.max_over_ranks(elapsed)
 
     if rank == 0:
         units = world * B * args.steps
@@ -151,7 +139,9 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(name)
+            per_unit = json.load(open(tpath)).get(name, {}).get("bytes_per_unit")
+            if per_unit:                 # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE) per launch, GB like achieved
+                traffic = per_unit * units_per_launch
         out = {
             "metric": "poly-mults/sec at n=2^17 (32-bit p)",
             "value": value,
@@ -184,8 +174,7 @@ def main():
 
     plan.close()
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":

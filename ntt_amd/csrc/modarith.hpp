@@ -18,6 +18,7 @@
 // Butterflies keep values in [0, 2p) when 4p <= 2^32 (Lazy = true) and in [0, p) otherwise.
 #pragma once
 #include <cstdint>
+#include <initializer_list>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>

@@ -1,0 +1,46 @@
+"""world_size-2 gloo test of the multi-process host path (ntt_amd.shard) on CPU."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+import orc
+from ntt_amd import shard
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_partition_matches_reference_mpi_rule():
+    # main-mpi.cc:657-660 with 4 primes
+    assert [shard.partition(4, 4, r) for r in range(4)] == [(0, 1), (1, 1), (2, 1), (3, 1)]
+    assert [shard.partition(4, 2, r) for r in range(2)] == [(0, 2), (2, 2)]
+    assert [shard.partition(4, 3, r) for r in range(3)] == [(0, 2), (2, 2), (4, 0)]
+    assert [shard.partition(4, 8, r) for r in range(8)] == [(0, 1), (1, 1), (2, 1), (3, 1)] + [(4, 0)] * 4
+    for total in (1, 7, 32, 1024):
+        for world in (1, 2, 3, 8):
+            parts = [shard.partition(total, world, r) for r in range(world)]
+            assert sum(c for _, c in parts) == total
+            covered = [u for s, c in parts for u in range(s, s + c)]
+            assert covered == list(range(total))
+    assert shard.rank_seed(100, 3, 1024) == 100 + 3 * 1024
+
+
+def test_two_ranks_gloo(tmp_path):
+    out = tmp_path / "result.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(HERE, "_gloo_worker.py"), str(out)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.load(open(out))
+    assert res["world"] == 2 and res["nunits"] == 7
+    assert abs(res["tmax"] - 0.10) < 1e-9            # max over ranks, not rank 0's own 0.05
+    assert res["elapsed"] >= 0.10                      # the closing barrier waits for the slow rank
+    n, p = 300, 998244353
+    for u in range(7):
+        a = (orc.splitmix64_np(0x20250711 + u, n) % np.uint64(p)).astype(np.uint32)
+        b = (orc.splitmix64_np(0x20250711 + (1 << 20) + u, n) % np.uint64(p)).astype(np.uint32)
+        assert res["sums"][str(u)] == int(orc.poly_multiply(a, b, p).astype(np.uint64).sum())

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_TAG (tools/profile.sh) into profiles/TAG_*.{csv,md,json}.
+
+Per kernel: launches, average duration (rocprofv3 --kernel-trace), and per-launch PMC averages.
+HBM traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are reported in KiB by
+rocprofv3 (unit correction x1024) and on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide
+coalesced streams (gfx950 correction x2 on the read side; our row kernels read 4 B per lane per
+instruction, 256 B per wave instruction, so the x2 figure is given beside the raw one and the
+raw..x2 interval is what DESIGN.md quotes).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    for k in ("col_kernel", "row_mul_kernel", "row_fwd_kernel", "row_inv_kernel", "small_kernel",
+              "permute_kernel", "crt_reduce_kernel", "crt_merge_kernel"):
+        if k in name:
+            tag = ""
+            if k == "col_kernel":
+                # template args <MM, LAZY, LOGN1, INVERSE, HALF>
+                m = re.search(r"col_kernel<[^,]+, *(\w+), *(\d+), *(\w+), *(\w+)>", name)
+                tag = "_inv" if m and m.group(3) == "true" else "_fwd"
+            return k + tag
+    return None
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    # kernel trace
+    dur = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = short(row["Kernel_Name"])
+            if k:
+                dur[k].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+    # copy the stats csv verbatim (it is small)
+    for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w").write(open(f).read())
+    # pmc
+    pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = short(row["Kernel_Name"])
+            if k:
+                pmc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    summary = {}
+    for k in sorted(dur):
+        d = dur[k]
+        s = {"launches": len(d), "avg_us": sum(d) / len(d), "min_us": min(d), "max_us": max(d),
+             "total_ms": sum(d) / 1e3}
+        for c, vals in pmc.get(k, {}).items():
+            s[c] = sum(vals) / len(vals)
+        if "FETCH_SIZE" in s and "WRITE_SIZE" in s:
+            s["hbm_read_bytes_raw"] = s["FETCH_SIZE"] * 1024
+            s["hbm_read_bytes_x2"] = s["FETCH_SIZE"] * 2048
+            s["hbm_write_bytes"] = s["WRITE_SIZE"] * 1024
+        summary[k] = s
+    json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1, sort_keys=True)
+    with open(os.path.join(dst, f"{tag}_summary.md"), "w") as out:
+        out.write(f"# rocprofv3 summary {tag}\n\n`rocprofv3 --kernel-trace --stats -- python3 bench.py "
+                  "--no-cpu-baseline --steps 5 --warmup 2` (durations) and separate `--pmc` passes "
+                  "(`--steps 1 --warmup 1`), see tools/profile.sh.  Per-launch averages.\n\n")
+        out.write("| kernel | launches | avg us | total ms | read MiB raw / x2 | write MiB | VALU insts/wave | "
+                  "LDS bank-conflict cyc / LDS active | TCC hit rate |\n|---|---|---|---|---|---|---|---|---|\n")
+        for k, s in summary.items():
+            rd = f"{s.get('hbm_read_bytes_raw', 0) / 2**20:.2f} / {s.get('hbm_read_bytes_x2', 0) / 2**20:.2f}"
+            wr = f"{s.get('hbm_write_bytes', 0) / 2**20:.2f}"
+            valu = s.get("SQ_INSTS_VALU", 0) / max(s.get("SQ_WAVES", 1), 1)
+            lds = f"{s.get('SQ_LDS_BANK_CONFLICT', 0):.0f} / {s.get('SQ_ACTIVE_INST_LDS', 0):.0f}"
+            hit = s.get("TCC_HIT_sum", 0) / max(s.get("TCC_HIT_sum", 0) + s.get("TCC_MISS_sum", 0), 1)
+            out.write(f"| {k} | {s['launches']} | {s['avg_us']:.1f} | {s['total_ms']:.2f} | {rd} | {wr} | "
+                      f"{valu:.0f} | {lds} | {hit:.2f} |\n")
+    print(open(os.path.join(dst, f"{tag}_summary.md")).read())
+
+
+if __name__ == "__main__":
+    main()
