@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--barrett", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunk", type=int, default=0, help="products per kernel launch (0 = library default)")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="do not bracket kernels with HIP events in the timed region (no roofline block)")
     args = ap.parse_args()
 
     import torch                      # device memory, streams and torch.distributed: plumbing
@@ -86,6 +89,8 @@ def main():
     dab = torch.zeros((B, stride), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
 
+    if args.chunk > 0:
+        os.environ["NTT_AMD_CHUNK"] = str(args.chunk)
     ctx = ntt_amd.Context(local_rank)
     kind = ntt_amd.BARRETT if args.barrett else ntt_amd.MONTGOMERY
     plan = ctx.plan(p, n, B, kind)
@@ -112,7 +117,7 @@ def main():
             print("bench: GPU result differs from the oracle", file=sys.stderr)
             sys.exit(1)
 
-    ctx.enable_kernel_timing(True)
+    ctx.enable_kernel_timing(not args.no_kernel_timing)
     barrier()
     sync()
     t0 = time.perf_counter()
@@ -131,6 +136,12 @@ def main():
         value = units / elapsed
         alg_bytes = 16 * n - 4                      # read a, read b, write ab
         # dominant kernel = largest share of device time in the timed region
+        if args.no_kernel_timing:
+            print(json.dumps({"value": value, "ms_per_step": 1e3 * elapsed / args.steps, "chunk": args.chunk}), flush=True)
+            plan.close()
+            ctx.close()
+            group.close()
+            return
         name, (tot_ms, launches) = max(((k, v) for k, v in ktimes.items() if v[1] > 0),
                                        key=lambda kv: kv[1][0])
         units_per_launch = B * args.steps / launches

@@ -163,6 +163,17 @@ static int build_tables(ntt_plan *pl)
         const uint32_t M = 1u << pl->level_logM[j], N1 = 1u << pl->level_log[j], S = M / N1;
         const uint32_t wM = h_powmod(wL, L / M, p), iwM = h_powmod(iwL, L / M, p);
         const bool innermost = (j == pl->nlevels - 1);
+        if (pl->level_log[j] >= 5) {                     // inner twiddles of the LDS-staged column kernel
+            const uint32_t wN = h_powmod(wL, L / N1, p), iwN = h_powmod(iwL, L / N1, p);
+            typename MM::tw_t f[64], b[64];
+            for (uint32_t r = 0; r < 4; ++r)
+                for (uint32_t ka = 0; ka < 16; ++ka) {
+                    f[r * 16 + ka] = MM::make_tw(h_powmod(wN, (uint64_t)r * ka, p), mp);
+                    b[r * 16 + ka] = MM::make_tw(h_powmod(iwN, (uint64_t)r * ka, p), mp);
+                }
+            pl->tw_in_fwd[j].assign((unsigned char *)f, (unsigned char *)f + sizeof(f));
+            pl->tw_in_inv[j].assign((unsigned char *)b, (unsigned char *)b + sizeof(b));
+        }
         int rc = upload_table<MM>(pl, power_table<MM>(wM, N1, S, 1, mp), &pl->tw_fwd[j]);
         if (rc) return rc;
         rc = upload_table<MM>(pl, power_table<MM>(iwM, N1, S, innermost ? scale_mul : 1, mp), &pl->tw_inv[j]);
@@ -214,9 +225,18 @@ static void col_pass(ntt_plan *pl, int level, bool inverse, bool half_in, const 
     a.canon = canon ? 1 : 0;
     fill_roots<MM>(a.roots, inverse ? pl->iroots : pl->roots);
     ntt_ctx *cx = pl->ctx;
+    const bool col16 = (inverse ? pl->col16_inv : pl->col16_fwd) && pl->level_log[level] >= 5;
+    if (col16) {
+        const auto &src = inverse ? pl->tw_in_inv[level] : pl->tw_in_fwd[level];
+        std::memcpy(a.tw_in, src.data(), sizeof(a.tw_in));
+    }
     cx->begin(inverse ? K_COL_INV : K_COL_FWD);
-    launch_col(pl->kind, pl->lazy, pl->level_log[level], inverse, half_in, &a, pl->mp,
-               pl->L >> pl->level_log[level], batch, nops, cx->stream);
+    if (col16)
+        launch_col16(pl->kind, pl->lazy, pl->level_log[level], inverse, half_in, &a, pl->mp,
+                     pl->L >> pl->level_log[level], batch, nops, cx->cur);
+    else
+        launch_col(pl->kind, pl->lazy, pl->level_log[level], inverse, half_in, &a, pl->mp,
+                   pl->L >> pl->level_log[level], batch, nops, cx->cur);
     cx->end();
 }
 
@@ -234,9 +254,9 @@ static void row_pass(ntt_plan *pl, int which, const uint32_t *a0, const uint32_t
     fill_roots<MM>(a.iroots, pl->iroots);
     ntt_ctx *cx = pl->ctx;
     cx->begin(which == 0 ? K_ROW_MUL : which == 1 ? K_ROW_FWD : K_ROW_INV);
-    if (which == 0) launch_row_mul(pl->kind, pl->lazy, &a, pl->mp, rows, cx->stream);
-    else if (which == 1) launch_row_fwd(pl->kind, pl->lazy, &a, pl->mp, rows, cx->stream);
-    else launch_row_inv(pl->kind, pl->lazy, &a, pl->mp, rows, cx->stream);
+    if (which == 0) launch_row_mul(pl->kind, pl->lazy, &a, pl->mp, rows, cx->cur);
+    else if (which == 1) launch_row_fwd(pl->kind, pl->lazy, &a, pl->mp, rows, cx->cur);
+    else launch_row_inv(pl->kind, pl->lazy, &a, pl->mp, rows, cx->cur);
     cx->end();
 }
 
@@ -256,7 +276,7 @@ static void small_pass(ntt_plan *pl, int mode, const uint32_t *a0, const uint32_
     a.mode = mode;
     ntt_ctx *cx = pl->ctx;
     cx->begin(K_SMALL);
-    launch_small(pl->kind, pl->lazy, &a, pl->mp, batch, cx->stream);
+    launch_small(pl->kind, pl->lazy, &a, pl->mp, batch, cx->cur);
     cx->end();
 }
 
@@ -266,13 +286,25 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
                            size_t ab_stride, int batch)
 {
     const uint32_t n = (uint32_t)pl->n, L = pl->L, out_len = 2 * n - 1;
+    pl->ctx->cur = pl->ctx->stream;
     if (pl->logL <= kRowLog) {
         small_pass<MM>(pl, 0, a, b, ab, n, ab_stride, n, out_len, (unsigned)batch);
         return NTT_OK;
     }
-    uint32_t *w0 = static_cast<uint32_t *>(pl->work0.ptr), *w1 = static_cast<uint32_t *>(pl->work1.ptr);
     const int m = pl->nlevels;
-    for (int c0 = 0; c0 < batch; c0 += pl->chunk) {
+    ntt_ctx *cx = pl->ctx;
+    const int nchunks = (batch + pl->chunk - 1) / pl->chunk;
+    const int lanes = std::min(std::min(pl->lanes, cx->nlanes), nchunks);
+    if (lanes > 1) {                                      // fork: side lanes start after prior work
+        (void)hipEventRecord(cx->fork_ev, cx->stream);
+        for (int l = 1; l < lanes; ++l) (void)hipStreamWaitEvent(cx->lane[l], cx->fork_ev, 0);
+    }
+    int ci = 0;
+    for (int c0 = 0; c0 < batch; c0 += pl->chunk, ++ci) {
+        const int l = ci % lanes;
+        cx->cur = l == 0 ? cx->stream : cx->lane[l];
+        uint32_t *w0 = static_cast<uint32_t *>(pl->work0.ptr) + (size_t)l * pl->chunk * L;
+        uint32_t *w1 = static_cast<uint32_t *>(pl->work1.ptr) + (size_t)l * pl->chunk * L;
         const unsigned cb = (unsigned)std::min(pl->chunk, batch - c0);
         const uint32_t *ca = a + (size_t)c0 * n, *cbp = b + (size_t)c0 * n;
         // forward column levels (both operands per launch); level 0 reads the caller's arrays with
@@ -288,6 +320,13 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
                          j == m - 1, pl->scale_mul, false, cb, 1);
         col_pass<MM>(pl, 0, true, false, w0, nullptr, ab + (size_t)c0 * ab_stride, nullptr, L, ab_stride,
                      L, out_len, pl->tw_inv[0], m == 1, pl->scale_mul, true, cb, 1);
+    }
+    cx->cur = cx->stream;
+    if (lanes > 1) {                                      // join
+        for (int l = 1; l < lanes; ++l) {
+            (void)hipEventRecord(cx->lane_done[l], cx->lane[l]);
+            (void)hipStreamWaitEvent(cx->stream, cx->lane_done[l], 0);
+        }
     }
     return NTT_OK;
 }
@@ -312,7 +351,7 @@ static void permute_pass(ntt_plan *pl, const uint32_t *src, uint32_t *dst, bool 
     pa.canon_p = (to_natural && pl->lazy) ? pl->p : 0;      // forward spectrum leaves the rows in [0, 2p)
     ntt_ctx *cx = pl->ctx;
     cx->begin(K_PERMUTE);
-    launch_permute(pa, batch, cx->stream);
+    launch_permute(pa, batch, cx->cur);
     cx->end();
 }
 
@@ -321,6 +360,7 @@ template <class MM>
 static int transform_device(ntt_plan *pl, uint32_t *data, int batch, bool inverse)
 {
     const uint32_t L = pl->L;
+    pl->ctx->cur = pl->ctx->stream;
     if (pl->logL <= kRowLog) {
         small_pass<MM>(pl, inverse ? 2 : 1, data, nullptr, data, L, L, L, L, (unsigned)batch);
         return NTT_OK;
@@ -368,13 +408,13 @@ void ntt_ctx::begin(int id)
 {
     if (!timing) return;
     Stamp s{id, grab_event(), grab_event()};
-    (void)hipEventRecord(s.e0, stream);
+    (void)hipEventRecord(s.e0, cur ? cur : stream);
     stamps.push_back(s);
 }
 void ntt_ctx::end()
 {
     if (!timing) return;
-    (void)hipEventRecord(stamps.back().e1, stream);
+    (void)hipEventRecord(stamps.back().e1, cur ? cur : stream);
 }
 int ntt_ctx::fold()
 {
@@ -419,6 +459,18 @@ int ntt_ctx_create(const int *device_ids, int ndev, ntt_ctx **out_ctx)
         return fail(NTT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
     cx->stream = cx->own_stream;
+    cx->cur = cx->stream;
+    int nl = 2;
+    if (const char *ev = std::getenv("NTT_AMD_STREAMS")) nl = std::atoi(ev);
+    cx->nlanes = std::max(1, std::min(nl, (int)ntt_ctx::kMaxLanes));
+    for (int l = 1; l < cx->nlanes; ++l) {
+        if (hipStreamCreateWithFlags(&cx->lane[l], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&cx->lane_done[l], hipEventDisableTiming) != hipSuccess) {
+            cx->nlanes = l;
+            break;
+        }
+    }
+    (void)hipEventCreateWithFlags(&cx->fork_ev, hipEventDisableTiming);
     *out_ctx = cx;
     return NTT_OK;
 }
@@ -428,6 +480,7 @@ int ntt_ctx_set_stream(ntt_ctx *ctx, void *hip_stream)
     if (!ctx) return fail(NTT_ERR_INVALID, "null context");
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    ctx->cur = ctx->stream;
     return NTT_OK;
 }
 void *ntt_ctx_stream(ntt_ctx *ctx) { return ctx ? static_cast<void *>(ctx->stream) : nullptr; }
@@ -487,6 +540,11 @@ int ntt_ctx_destroy(ntt_ctx *ctx)
     ctx->stage_out.release();
     for (auto &s : ctx->stamps) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (int l = 1; l < ctx->nlanes; ++l) {
+        if (ctx->lane[l]) (void)hipStreamDestroy(ctx->lane[l]);
+        if (ctx->lane_done[l]) (void)hipEventDestroy(ctx->lane_done[l]);
+    }
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return NTT_OK;
@@ -522,6 +580,11 @@ int ntt_plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind,
     pl->lazy = p < (1u << 30);
     if (const char *e = std::getenv("NTT_AMD_FORCE_STRICT"))
         if (e[0] == '1') pl->lazy = false;
+    if (const char *e = std::getenv("NTT_AMD_COL16")) {
+        const int v = std::atoi(e);
+        pl->col16_fwd = v & 1;
+        pl->col16_inv = v & 2;
+    }
     if (logL > kRowLog) {
         const int c = logL - kRowLog;
         const int m = (c + kMaxColLog - 1) / kMaxColLog;
@@ -532,17 +595,19 @@ int ntt_plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind,
             logM -= pl->level_log[j];
         }
         pl->nlevels = m;
-        // work buffers: two operands per product, `chunk` products in flight.  The default keeps
-        // the intermediates of one chunk (2 * L * 4 B per product) well inside the 256 MiB
-        // Infinity Cache so that the three passes hand data over on-die.
+        // work buffers: two operands per product, `chunk` products per launch and per lane.
+        // Measured (profiles/sweep_chunk_r01.txt): throughput rises with the chunk up to ~128
+        // products (fewer launches, smaller tail rounds) and is insensitive to whether the
+        // intermediates fit the 256 MiB Infinity Cache, so the default is 256 MiB per lane.
         size_t per = (size_t)L * sizeof(uint32_t);
-        long chunk = (long)((64u << 20) / (2 * per));
+        long chunk = (long)((256u << 20) / (2 * per));
         if (const char *e = std::getenv("NTT_AMD_CHUNK")) chunk = std::atol(e);
         chunk = std::max<long>(1, std::min<long>(chunk, batch));
         chunk = std::min<long>(chunk, 65535);
         pl->chunk = (int)chunk;
-        int rc = pl->work0.ensure(per * chunk);
-        if (rc == NTT_OK) rc = pl->work1.ensure(per * chunk);
+        pl->lanes = (int)std::min<long>(ctx->nlanes, (batch + chunk - 1) / chunk);
+        int rc = pl->work0.ensure(per * chunk * pl->lanes);
+        if (rc == NTT_OK) rc = pl->work1.ensure(per * chunk * pl->lanes);
         if (rc) { ntt_plan *raw = pl.release(); ntt_plan_destroy(raw); return rc; }
     } else {
         pl->chunk = batch;

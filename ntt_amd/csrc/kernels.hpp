@@ -33,6 +33,7 @@ struct ColArgs {
     int use_scale0;
     int canon;                           // 1: final pass, store canonical residues
     Roots64<MM> roots;
+    typename MM::tw_t tw_in[64];         // col16 kernels: inner twiddles w_N1^(+-r*ka), index r*16 + ka
 };
 
 template <class MM>
@@ -72,6 +73,9 @@ struct CrtConsts {
 void launch_col(int kind, bool lazy, int logN1, bool inverse, bool half_in, const void *args,
                 const ModParams &mp, unsigned cols_per_row, unsigned batch, unsigned nops,
                 hipStream_t s);
+void launch_col16(int kind, bool lazy, int logN1, bool inverse, bool half_in, const void *args,
+                  const ModParams &mp, unsigned cols_per_row, unsigned batch, unsigned nops,
+                  hipStream_t s);
 void launch_row_mul(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);
 void launch_row_fwd(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);
 void launch_row_inv(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);

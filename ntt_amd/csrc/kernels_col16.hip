@@ -1,0 +1,125 @@
+// kernels_col16.hip -- LDS-staged column pass for N1 = 32 and 64 (N1 = 16 * R, R = 2 or 4), gfx950.
+//
+// The register-only column kernel (kernels_col.hip) needs ~230 VGPRs for 64 points per thread
+// (2 waves per SIMD) and rocprofv3 shows it ~55 % VALU-busy.  Here a workgroup of 256 threads
+// owns a tile of C = 256/R columns x N1 rows and every thread keeps 16 points:
+//   pass 1: thread (c, r) loads rows 4a + r (resp. 2a + r), a < 16, runs a 16-point register NTT
+//           over a and multiplies by the wave-uniform inner twiddle w_N1^(r*ka)   (SGPR operands)
+//   LDS   : one exchange of the 16 KiB tile, laid out [r][ka][c]: reads and writes are
+//           lane-consecutive, bank-conflict free, one barrier
+//   pass 2: thread (c, q) takes the ka in [q*16/R, (q+1)*16/R), runs the radix-R NTT over r, and
+//           owns output rows k = ka + 16*kr, which it multiplies by the 4-step twiddle and stores
+// Same arithmetic as col_kernel (X[ka + 16 kr] = sum_r w_R^(r kr) w_N1^(r ka) sum_a x[R a + r] w_16^(a ka)),
+// ~45 VGPRs, 8 waves per SIMD.  Across the 64 lanes of a wave every global access is 256 contiguous
+// bytes, as before.
+#include "device_ntt.hpp"
+
+namespace ntt {
+
+template <class MM, bool LAZY, int LOGR, bool INVERSE, bool HALF>
+__global__ void __launch_bounds__(256) col16_kernel(const ColArgs<MM> a, const ModParams m)
+{
+    using O = Ops<MM, LAZY>;
+    using tw_t = typename MM::tw_t;
+    constexpr int R = 1 << LOGR;             // 2 or 4
+    constexpr int LOGC = 8 - LOGR;           // columns per workgroup
+    constexpr int C = 1 << LOGC;
+    constexpr int KA = 16 / R;               // ka values per thread in pass 2
+    __shared__ uint32_t lds[4096];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t cl = tid & (C - 1);
+    const int r = __builtin_amdgcn_readfirstlane(tid >> LOGC);     // wave-uniform
+    const uint32_t c = blockIdx.x * C + cl;                        // column id within the row
+    const uint32_t S = 1u << a.logS;
+    const uint32_t i2 = c & (S - 1);
+    const uint32_t base = ((c >> a.logS) << a.logM) + i2;          // blk * M + i2
+    const int op = blockIdx.z;
+    const uint32_t *__restrict__ in = a.in[op] + (size_t)blockIdx.y * a.in_stride;
+    uint32_t *__restrict__ out = a.out[op] + (size_t)blockIdx.y * a.out_stride;
+    const tw_t *__restrict__ tw = a.tw + i2;
+
+    // ---- pass 1: rows R*a + r ----------------------------------------------------------------
+    uint32_t x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (HALF && j >= 8) {
+            x[j] = 0;
+        } else {
+            const uint32_t row = (uint32_t)(R * j + r);
+            const uint32_t idx = base + (row << a.logS);
+            uint32_t v = idx < a.in_len ? in[idx] : 0u;
+            if constexpr (INVERSE) {
+                if (row == 0) { if (a.use_scale0) v = O::mul_tw(v, a.scale0, m); }
+                else v = O::mul_tw(v, tw[(size_t)row << a.logS], m);
+            }
+            x[j] = v;
+        }
+    }
+    reg_ntt<MM, LAZY, 4, HALF>(x, a.roots, m);
+    if (r != 0) {                                                  // wave-uniform branch
+#pragma unroll
+        for (int ka = 1; ka < 16; ++ka) x[ka] = O::mul_tw(x[ka], a.tw_in[r * 16 + ka], m);
+    }
+#pragma unroll
+    for (int ka = 0; ka < 16; ++ka) lds[(r * 16 + ka) * C + cl] = x[ka];
+    __syncthreads();
+
+    // ---- pass 2: radix-R over r for ka in [q*KA, (q+1)*KA) ---------------------------------------
+    const int q = r;
+#pragma unroll
+    for (int j = 0; j < KA; ++j) {
+        const int ka = q * KA + j;
+        uint32_t y[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) y[rr] = lds[(rr * 16 + ka) * C + cl];
+        reg_ntt<MM, LAZY, LOGR, false>(y, a.roots, m);
+#pragma unroll
+        for (int kr = 0; kr < R; ++kr) {
+            const uint32_t row = (uint32_t)(ka + 16 * kr);
+            uint32_t v = y[kr];
+            if constexpr (!INVERSE) {
+                if (row != 0) v = O::mul_tw(v, tw[(size_t)row << a.logS], m);
+            }
+            const uint32_t idx = base + (row << a.logS);
+            if (idx < a.out_len) out[idx] = a.canon ? O::canon(v, m) : v;
+        }
+    }
+}
+
+template <class MM, bool LAZY, int LOGR>
+static void launch_t(bool inverse, bool half_in, const ColArgs<MM> &a, const ModParams &mp, dim3 grid,
+                     hipStream_t s)
+{
+    if (inverse)
+        hipLaunchKernelGGL((col16_kernel<MM, LAZY, LOGR, true, false>), grid, dim3(256), 0, s, a, mp);
+    else if (half_in)
+        hipLaunchKernelGGL((col16_kernel<MM, LAZY, LOGR, false, true>), grid, dim3(256), 0, s, a, mp);
+    else
+        hipLaunchKernelGGL((col16_kernel<MM, LAZY, LOGR, false, false>), grid, dim3(256), 0, s, a, mp);
+}
+
+template <class MM, bool LAZY>
+static void launch_l(int logN1, bool inverse, bool half_in, const ColArgs<MM> &a, const ModParams &mp,
+                     unsigned cols_per_row, unsigned batch, unsigned nops, hipStream_t s)
+{
+    if (logN1 == 6) launch_t<MM, LAZY, 2>(inverse, half_in, a, mp, dim3(cols_per_row / 64, batch, nops), s);
+    else launch_t<MM, LAZY, 1>(inverse, half_in, a, mp, dim3(cols_per_row / 128, batch, nops), s);
+}
+
+void launch_col16(int kind, bool lazy, int logN1, bool inverse, bool half_in, const void *args,
+                  const ModParams &mp, unsigned cols_per_row, unsigned batch, unsigned nops,
+                  hipStream_t s)
+{
+    if (kind == 0) {
+        const auto &a = *static_cast<const ColArgs<Mont32> *>(args);
+        if (lazy) launch_l<Mont32, true>(logN1, inverse, half_in, a, mp, cols_per_row, batch, nops, s);
+        else launch_l<Mont32, false>(logN1, inverse, half_in, a, mp, cols_per_row, batch, nops, s);
+    } else {
+        const auto &a = *static_cast<const ColArgs<Barrett32> *>(args);
+        if (lazy) launch_l<Barrett32, true>(logN1, inverse, half_in, a, mp, cols_per_row, batch, nops, s);
+        else launch_l<Barrett32, false>(logN1, inverse, half_in, a, mp, cols_per_row, batch, nops, s);
+    }
+}
+
+}  // namespace ntt

@@ -20,13 +20,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    for k in ("col_kernel", "row_mul_kernel", "row_fwd_kernel", "row_inv_kernel", "small_kernel",
+    for k in ("col16_kernel", "col_kernel", "row_mul_kernel", "row_fwd_kernel", "row_inv_kernel", "small_kernel",
               "permute_kernel", "crt_reduce_kernel", "crt_merge_kernel"):
         if k in name:
             tag = ""
-            if k == "col_kernel":
+            if k in ("col_kernel", "col16_kernel"):
                 # template args <MM, LAZY, LOGN1, INVERSE, HALF>
-                m = re.search(r"col_kernel<[^,]+, *(\w+), *(\d+), *(\w+), *(\w+)>", name)
+                m = re.search(r"col(?:16)?_kernel<[^,]+, *(\w+), *(\d+), *(\w+), *(\w+)>", name)
                 tag = "_inv" if m and m.group(3) == "true" else "_fwd"
             return k + tag
     return None
