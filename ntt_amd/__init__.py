@@ -27,7 +27,8 @@ if importlib.util.find_spec("torch") is not None:
     import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libntt_amd.so")
+# NTT_AMD_LIB selects another build of the same library (A/B experiments under ntt_amd/variants/)
+_LIB_PATH = os.environ.get("NTT_AMD_LIB") or os.path.join(_HERE, "libntt_amd.so")
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM, ERR_IO, ERR_MISMATCH = range(7)
 MONTGOMERY, BARRETT = 0, 1

@@ -1,0 +1,88 @@
+// col16_body.hpp -- device body of the LDS-staged column pass (see kernels_col16.hip), shared by the
+// stand-alone kernel and the fused pipeline kernel (kernels_pipe.hip).
+#pragma once
+#include "device_ntt.hpp"
+
+namespace ntt {
+
+// Body of the LDS-staged column pass for one tile: `bx` = tile index within the row (blockIdx.x
+// of the stand-alone kernel), `by` = batch row, `op` = operand.  `lds` holds >= 4096 words.
+template <class MM, bool LAZY, int LOGR, bool INVERSE, bool HALF>
+__device__ __forceinline__ void col16_body(const ColArgs<MM> &a, const ModParams &m, uint32_t *lds,
+                                           const uint32_t bx, const uint32_t by, const int op)
+{
+    using O = Ops<MM, LAZY>;
+    using tw_t = typename MM::tw_t;
+    constexpr int R = 1 << LOGR;             // 2 or 4
+    constexpr int LOGC = 8 - LOGR;           // columns per workgroup
+    constexpr int C = 1 << LOGC;
+    constexpr int KA = 16 / R;               // ka values per thread in pass 2
+    const uint32_t tid = threadIdx.x;
+    const uint32_t cl = tid & (C - 1);
+    const int r = __builtin_amdgcn_readfirstlane(tid >> LOGC);     // wave-uniform
+    const uint32_t c = bx * C + cl;                        // column id within the row
+    const uint32_t S = 1u << a.logS;
+    const uint32_t i2 = c & (S - 1);
+    const uint32_t base = ((c >> a.logS) << a.logM) + i2;          // blk * M + i2
+        const uint32_t *__restrict__ in = a.in[op] + (size_t)by * a.in_stride;
+    uint32_t *__restrict__ out = a.out[op] + (size_t)by * a.out_stride;
+    const tw_t *__restrict__ tw = a.tw + i2;
+
+    // ---- pass 1: rows R*a + r ----------------------------------------------------------------
+    uint32_t x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (HALF && j >= 8) {
+            x[j] = 0;
+        } else {
+            const uint32_t row = (uint32_t)(R * j + r);
+            const uint32_t idx = base + (row << a.logS);
+            uint32_t v = idx < a.in_len ? in[idx] : 0u;
+            if constexpr (INVERSE) {
+                // inputs may be loose: every row is multiplied, except row 0 of an outer level
+                if (row == 0) v = a.use_scale0 ? O::mul_tw(v, a.scale0, m) : O::tighten(v, m);
+                else v = O::mul_tw(v, tw[(size_t)row << a.logS], m);
+            }
+            x[j] = v;
+        }
+    }
+    reg_ntt<MM, LAZY, 4, HALF, true>(x, a.roots, m);              // loose outputs
+    x[0] = O::tighten(x[0], m);
+    if (r != 0) {                                                  // wave-uniform branch
+#pragma unroll
+        for (int ka = 1; ka < 16; ++ka) x[ka] = O::mul_tw(x[ka], a.tw_in[r * 16 + ka], m);
+    } else {
+#pragma unroll
+        for (int ka = 1; ka < 16; ++ka) x[ka] = O::tighten(x[ka], m);
+    }
+#pragma unroll
+    for (int ka = 0; ka < 16; ++ka) lds[(r * 16 + ka) * C + cl] = x[ka];
+    __syncthreads();
+
+    // ---- pass 2: radix-R over r for ka in [q*KA, (q+1)*KA) ---------------------------------------
+    const int q = r;
+#pragma unroll
+    for (int j = 0; j < KA; ++j) {
+        const int ka = q * KA + j;
+        uint32_t y[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) y[rr] = lds[(rr * 16 + ka) * C + cl];
+        reg_ntt<MM, LAZY, LOGR, false, true>(y, a.roots, m);      // loose outputs
+#pragma unroll
+        for (int kr = 0; kr < R; ++kr) {
+            const uint32_t row = (uint32_t)(ka + 16 * kr);
+            uint32_t v = y[kr];
+            if constexpr (!INVERSE) {
+                v = row != 0 ? O::mul_tw(v, tw[(size_t)row << a.logS], m) : O::tighten(v, m);
+            } else {
+                // non-final levels hand loose values to the next level; the final one canonicalises
+                if (a.canon) v = O::canon(O::tighten(v, m), m);
+            }
+            const uint32_t idx = base + (row << a.logS);
+            if (idx < a.out_len) out[idx] = v;
+        }
+    }
+}
+
+
+}  // namespace ntt

@@ -37,6 +37,11 @@ struct Ops {
     {
         return LAZY ? csub(x, m.p) : x;
     }
+    // loose [0, 2*bound) -> [0, bound)
+    static __device__ __forceinline__ uint32_t tighten(uint32_t x, const ModParams &m)
+    {
+        return csub(x, bound(m));
+    }
     // variable * variable (pointwise product).  Montgomery: result carries a factor R^-1 that
     // the host folds into the inverse scale constant.
     static __device__ __forceinline__ uint32_t mul(uint32_t a, uint32_t b, const ModParams &m)
@@ -62,7 +67,11 @@ __host__ __device__ constexpr int bitrev_c(int x, int bits)
 // powers are the stride-(64/N) entries of the w_64 table; forward or inverse table).
 // Decimation in frequency; the final bit reversal is a compile-time register renaming.
 // HALF: x[j] == 0 for j >= N/2 (zero-padded operand), the first stage then needs no add/sub.
-template <class MM, bool LAZY, int LOGN, bool HALF>
+// LOOSE: the last stage skips its conditional subtractions, so outputs lie in [0, 2*bound)
+// ([0, 4p) lazy, [0, 2p) strict).  Every consumer either multiplies the value by a twiddle
+// (mul_tw takes any u32 and reduces for free) or applies Ops::tighten -- this removes 16 of the
+// ~47 conditional subtractions of a 16-point transform.
+template <class MM, bool LAZY, int LOGN, bool HALF, bool LOOSE = false>
 __device__ __forceinline__ void reg_ntt(uint32_t (&x)[1 << LOGN], const Roots64<MM> &roots,
                                         const ModParams &m)
 {
@@ -81,6 +90,9 @@ __device__ __forceinline__ void reg_ntt(uint32_t (&x)[1 << LOGN], const Roots64<
                 if (HALF && s == 0) {
                     // v == 0: sum = u, difference = u
                     x[blk + j + half] = (j == 0) ? u : O::mul_tw(u, roots.w[j * step], m);
+                } else if (LOOSE && s == LOGN - 1) {
+                    x[blk + j] = u + v;                              // half == 1: j == 0 only
+                    x[blk + j + half] = O::sub_raw(u, v, m);
                 } else {
                     x[blk + j] = O::add(u, v, m);
                     x[blk + j + half] = (j == 0) ? O::sub(u, v, m)

@@ -16,7 +16,7 @@
 namespace ntt {
 
 const char *const kKernelNames[K_COUNT] = {"col_fwd", "row_mul", "col_inv", "row_fwd", "row_inv",
-                                           "small", "permute", "crt_reduce", "crt_merge"};
+                                           "small", "permute", "crt_reduce", "crt_merge", "pipe"};
 
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
@@ -206,11 +206,10 @@ static void fill_roots(Roots64<MM> &dst, const std::vector<unsigned char> &src)
 }
 
 template <class MM>
-static void col_pass(ntt_plan *pl, int level, bool inverse, bool half_in, const uint32_t *in0,
-                     const uint32_t *in1, uint32_t *out0, uint32_t *out1, size_t in_stride,
-                     size_t out_stride, uint32_t in_len, uint32_t out_len, const void *tw,
-                     bool use_scale0, const std::vector<unsigned char> &scale0, bool canon,
-                     unsigned batch, unsigned nops)
+static ColArgs<MM> fill_col(ntt_plan *pl, int level, bool inverse, const uint32_t *in0, const uint32_t *in1,
+                            uint32_t *out0, uint32_t *out1, size_t in_stride, size_t out_stride,
+                            uint32_t in_len, uint32_t out_len, const void *tw, bool use_scale0,
+                            const std::vector<unsigned char> &scale0, bool canon)
 {
     ColArgs<MM> a{};
     a.in[0] = in0; a.in[1] = in1;
@@ -224,12 +223,24 @@ static void col_pass(ntt_plan *pl, int level, bool inverse, bool half_in, const 
     if (use_scale0) std::memcpy(&a.scale0, scale0.data(), sizeof(a.scale0));
     a.canon = canon ? 1 : 0;
     fill_roots<MM>(a.roots, inverse ? pl->iroots : pl->roots);
-    ntt_ctx *cx = pl->ctx;
-    const bool col16 = (inverse ? pl->col16_inv : pl->col16_fwd) && pl->level_log[level] >= 5;
-    if (col16) {
+    if (pl->level_log[level] >= 5) {
         const auto &src = inverse ? pl->tw_in_inv[level] : pl->tw_in_fwd[level];
         std::memcpy(a.tw_in, src.data(), sizeof(a.tw_in));
     }
+    return a;
+}
+
+template <class MM>
+static void col_pass(ntt_plan *pl, int level, bool inverse, bool half_in, const uint32_t *in0,
+                     const uint32_t *in1, uint32_t *out0, uint32_t *out1, size_t in_stride,
+                     size_t out_stride, uint32_t in_len, uint32_t out_len, const void *tw,
+                     bool use_scale0, const std::vector<unsigned char> &scale0, bool canon,
+                     unsigned batch, unsigned nops)
+{
+    ColArgs<MM> a = fill_col<MM>(pl, level, inverse, in0, in1, out0, out1, in_stride, out_stride, in_len,
+                                 out_len, tw, use_scale0, scale0, canon);
+    ntt_ctx *cx = pl->ctx;
+    const bool col16 = (inverse ? pl->col16_inv : pl->col16_fwd) && pl->level_log[level] >= 5;
     cx->begin(inverse ? K_COL_INV : K_COL_FWD);
     if (col16)
         launch_col16(pl->kind, pl->lazy, pl->level_log[level], inverse, half_in, &a, pl->mp,
@@ -241,8 +252,7 @@ static void col_pass(ntt_plan *pl, int level, bool inverse, bool half_in, const 
 }
 
 template <class MM>
-static void row_pass(ntt_plan *pl, int which, const uint32_t *a0, const uint32_t *b0, uint32_t *out,
-                     unsigned rows)
+static RowArgs<MM> fill_row(ntt_plan *pl, const uint32_t *a0, const uint32_t *b0, uint32_t *out)
 {
     RowArgs<MM> a{};
     a.a = a0; a.b = b0; a.out = out;
@@ -252,6 +262,57 @@ static void row_pass(ntt_plan *pl, int which, const uint32_t *a0, const uint32_t
     a.itwB = static_cast<const typename MM::tw_t *>(pl->itwB);
     fill_roots<MM>(a.roots, pl->roots);
     fill_roots<MM>(a.iroots, pl->iroots);
+    return a;
+}
+
+// Software-pipelined multiply (kernels_pipe.hip): launch t runs F(chunk t), R(chunk t-1), I(chunk t-2).
+template <class MM>
+static int multiply_pipelined(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
+                              size_t ab_stride, int batch)
+{
+    const uint32_t n = (uint32_t)pl->n, L = pl->L, out_len = 2 * n - 1, per = L >> kRowLog;
+    ntt_ctx *cx = pl->ctx;
+    const int K = (batch + pl->chunk - 1) / pl->chunk;
+    auto cb_of = [&](int c) { return (uint32_t)std::min(pl->chunk, batch - c * pl->chunk); };
+    auto w0_of = [&](int c) { return static_cast<uint32_t *>(pl->work0.ptr) + (size_t)(c % 3) * pl->chunk * L; };
+    auto w1_of = [&](int c) { return static_cast<uint32_t *>(pl->work1.ptr) + (size_t)(c % 3) * pl->chunk * L; };
+    for (int t = 0; t < K + 2; ++t) {
+        PipeArgs<MM> pa{};
+        pa.groups_per_product = per;
+        if (t < K) {
+            const size_t c0 = (size_t)t * pl->chunk;
+            pa.f = fill_col<MM>(pl, 0, false, a + c0 * n, b + c0 * n, w0_of(t), w1_of(t), n, L, n, L,
+                                pl->tw_fwd[0], false, {}, false);
+            pa.groups_f = cb_of(t) * per;
+        }
+        if (t >= 1 && t - 1 < K) {
+            pa.r = fill_row<MM>(pl, w0_of(t - 1), w1_of(t - 1), w0_of(t - 1));
+            pa.groups_r = cb_of(t - 1) * per;
+        }
+        if (t >= 2) {
+            const size_t c0 = (size_t)(t - 2) * pl->chunk;
+            pa.i = fill_col<MM>(pl, 0, true, w0_of(t - 2), nullptr, ab + c0 * ab_stride, nullptr, L, ab_stride,
+                                L, out_len, pl->tw_inv[0], true, pl->scale_mul, true);
+            pa.groups_i = cb_of(t - 2) * per;
+        }
+        static const int dbg_mask = std::getenv("NTT_AMD_PIPE_MASK") ? std::atoi(std::getenv("NTT_AMD_PIPE_MASK")) : 7;
+        if (!(dbg_mask & 1)) pa.groups_f = 0;      // timing experiments only: results are wrong
+        if (!(dbg_mask & 2)) pa.groups_r = 0;
+        if (!(dbg_mask & 4)) pa.groups_i = 0;
+        const unsigned groups = std::max(pa.groups_f, std::max(pa.groups_r, pa.groups_i));
+        if (groups == 0) continue;
+        cx->begin(K_PIPE);
+        launch_pipe(pl->kind, pl->lazy, pl->level_log[0], &pa, pl->mp, groups, cx->cur);
+        cx->end();
+    }
+    return NTT_OK;
+}
+
+template <class MM>
+static void row_pass(ntt_plan *pl, int which, const uint32_t *a0, const uint32_t *b0, uint32_t *out,
+                     unsigned rows)
+{
+    RowArgs<MM> a = fill_row<MM>(pl, a0, b0, out);
     ntt_ctx *cx = pl->ctx;
     cx->begin(which == 0 ? K_ROW_MUL : which == 1 ? K_ROW_FWD : K_ROW_INV);
     if (which == 0) launch_row_mul(pl->kind, pl->lazy, &a, pl->mp, rows, cx->cur);
@@ -291,6 +352,7 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
         small_pass<MM>(pl, 0, a, b, ab, n, ab_stride, n, out_len, (unsigned)batch);
         return NTT_OK;
     }
+    if (pl->pipe) return multiply_pipelined<MM>(pl, a, b, ab, ab_stride, batch);
     const int m = pl->nlevels;
     ntt_ctx *cx = pl->ctx;
     const int nchunks = (batch + pl->chunk - 1) / pl->chunk;
@@ -598,16 +660,22 @@ int ntt_plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind,
         // work buffers: two operands per product, `chunk` products per launch and per lane.
         // Measured (profiles/sweep_chunk_r01.txt): throughput rises with the chunk up to ~128
         // products (fewer launches, smaller tail rounds) and is insensitive to whether the
-        // intermediates fit the 256 MiB Infinity Cache, so the default is 256 MiB per lane.
+        // intermediates fit the 256 MiB Infinity Cache, so the default is 128 MiB per lane (64 products at L = 2^18, the best of tools/sweep_final.sh).
         size_t per = (size_t)L * sizeof(uint32_t);
-        long chunk = (long)((256u << 20) / (2 * per));
+        long chunk = (long)((128u << 20) / (2 * per));
         if (const char *e = std::getenv("NTT_AMD_CHUNK")) chunk = std::atol(e);
         chunk = std::max<long>(1, std::min<long>(chunk, batch));
         chunk = std::min<long>(chunk, 65535);
         pl->chunk = (int)chunk;
         pl->lanes = (int)std::min<long>(ctx->nlanes, (batch + chunk - 1) / chunk);
-        int rc = pl->work0.ensure(per * chunk * pl->lanes);
-        if (rc == NTT_OK) rc = pl->work1.ensure(per * chunk * pl->lanes);
+        // Off by default: measured on MI355X the fused launch only matches the three separate
+        // kernels (roles do not overlap: F+R+I together take the sum of their solo times, see
+        // DESIGN.md section 8), so the simpler path stays the default.  NTT_AMD_PIPE=1 enables it.
+        pl->pipe = false;
+        if (const char *e = std::getenv("NTT_AMD_PIPE")) pl->pipe = e[0] == '1' && m == 1 && pl->level_log[0] >= 5;
+        const long slots = pl->pipe ? std::min<long>(3, (batch + chunk - 1) / chunk) : pl->lanes;
+        int rc = pl->work0.ensure(per * chunk * slots);
+        if (rc == NTT_OK) rc = pl->work1.ensure(per * chunk * slots);
         if (rc) { ntt_plan *raw = pl.release(); ntt_plan_destroy(raw); return rc; }
     } else {
         pl->chunk = batch;

@@ -45,6 +45,16 @@ struct RowArgs {
     Roots64<MM> roots, iroots;
 };
 
+// One launch of the software-pipelined fused kernel (kernels_pipe.hip): forward columns of
+// chunk t, row multiply of chunk t-1, inverse columns of chunk t-2.  groups_* = number of column
+// tiles / rows each role owns in this launch (0 = role idle while the pipeline fills or drains).
+template <class MM>
+struct PipeArgs {
+    ColArgs<MM> f, i;
+    RowArgs<MM> r;
+    uint32_t groups_f, groups_r, groups_i, groups_per_product;
+};
+
 template <class MM>
 struct SmallArgs {
     const uint32_t *a, *b;
@@ -76,6 +86,8 @@ void launch_col(int kind, bool lazy, int logN1, bool inverse, bool half_in, cons
 void launch_col16(int kind, bool lazy, int logN1, bool inverse, bool half_in, const void *args,
                   const ModParams &mp, unsigned cols_per_row, unsigned batch, unsigned nops,
                   hipStream_t s);
+void launch_pipe(int kind, bool lazy, int logN1, const void *args, const ModParams &mp, unsigned groups,
+                 hipStream_t s);
 void launch_row_mul(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);
 void launch_row_fwd(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);
 void launch_row_inv(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);

@@ -41,19 +41,24 @@ __global__ void __launch_bounds__(256) col_kernel(const ColArgs<MM> a, const Mod
         }
     }
     if constexpr (INVERSE) {
-        if (a.use_scale0) x[0] = O::mul_tw(x[0], a.scale0, m);
+        // inputs may be loose: every row is multiplied, except row 0 of an outer level
+        x[0] = a.use_scale0 ? O::mul_tw(x[0], a.scale0, m) : O::tighten(x[0], m);
 #pragma unroll
         for (int k1 = 1; k1 < N1; ++k1) x[k1] = O::mul_tw(x[k1], tw[(size_t)k1 << a.logS], m);
     }
-    reg_ntt<MM, LAZY, LOGN1, HALF>(x, a.roots, m);
+    reg_ntt<MM, LAZY, LOGN1, HALF, true>(x, a.roots, m);          // loose outputs
     if constexpr (!INVERSE) {
+        x[0] = O::tighten(x[0], m);
 #pragma unroll
         for (int k1 = 1; k1 < N1; ++k1) x[k1] = O::mul_tw(x[k1], tw[(size_t)k1 << a.logS], m);
     }
 #pragma unroll
     for (int k1 = 0; k1 < N1; ++k1) {
         const uint32_t idx = base + ((uint32_t)k1 << a.logS);
-        if (idx < a.out_len) out[idx] = a.canon ? O::canon(x[k1], m) : x[k1];
+        // inverse: non-final levels hand loose values to the next level; the final one canonicalises
+        uint32_t v = x[k1];
+        if (INVERSE && a.canon) v = O::canon(O::tighten(v, m), m);
+        if (idx < a.out_len) out[idx] = v;
     }
 }
 

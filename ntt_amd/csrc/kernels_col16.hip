@@ -12,79 +12,15 @@
 // Same arithmetic as col_kernel (X[ka + 16 kr] = sum_r w_R^(r kr) w_N1^(r ka) sum_a x[R a + r] w_16^(a ka)),
 // ~45 VGPRs, 8 waves per SIMD.  Across the 64 lanes of a wave every global access is 256 contiguous
 // bytes, as before.
-#include "device_ntt.hpp"
+#include "col16_body.hpp"
 
 namespace ntt {
 
 template <class MM, bool LAZY, int LOGR, bool INVERSE, bool HALF>
 __global__ void __launch_bounds__(256) col16_kernel(const ColArgs<MM> a, const ModParams m)
 {
-    using O = Ops<MM, LAZY>;
-    using tw_t = typename MM::tw_t;
-    constexpr int R = 1 << LOGR;             // 2 or 4
-    constexpr int LOGC = 8 - LOGR;           // columns per workgroup
-    constexpr int C = 1 << LOGC;
-    constexpr int KA = 16 / R;               // ka values per thread in pass 2
     __shared__ uint32_t lds[4096];
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t cl = tid & (C - 1);
-    const int r = __builtin_amdgcn_readfirstlane(tid >> LOGC);     // wave-uniform
-    const uint32_t c = blockIdx.x * C + cl;                        // column id within the row
-    const uint32_t S = 1u << a.logS;
-    const uint32_t i2 = c & (S - 1);
-    const uint32_t base = ((c >> a.logS) << a.logM) + i2;          // blk * M + i2
-    const int op = blockIdx.z;
-    const uint32_t *__restrict__ in = a.in[op] + (size_t)blockIdx.y * a.in_stride;
-    uint32_t *__restrict__ out = a.out[op] + (size_t)blockIdx.y * a.out_stride;
-    const tw_t *__restrict__ tw = a.tw + i2;
-
-    // ---- pass 1: rows R*a + r ----------------------------------------------------------------
-    uint32_t x[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        if (HALF && j >= 8) {
-            x[j] = 0;
-        } else {
-            const uint32_t row = (uint32_t)(R * j + r);
-            const uint32_t idx = base + (row << a.logS);
-            uint32_t v = idx < a.in_len ? in[idx] : 0u;
-            if constexpr (INVERSE) {
-                if (row == 0) { if (a.use_scale0) v = O::mul_tw(v, a.scale0, m); }
-                else v = O::mul_tw(v, tw[(size_t)row << a.logS], m);
-            }
-            x[j] = v;
-        }
-    }
-    reg_ntt<MM, LAZY, 4, HALF>(x, a.roots, m);
-    if (r != 0) {                                                  // wave-uniform branch
-#pragma unroll
-        for (int ka = 1; ka < 16; ++ka) x[ka] = O::mul_tw(x[ka], a.tw_in[r * 16 + ka], m);
-    }
-#pragma unroll
-    for (int ka = 0; ka < 16; ++ka) lds[(r * 16 + ka) * C + cl] = x[ka];
-    __syncthreads();
-
-    // ---- pass 2: radix-R over r for ka in [q*KA, (q+1)*KA) ---------------------------------------
-    const int q = r;
-#pragma unroll
-    for (int j = 0; j < KA; ++j) {
-        const int ka = q * KA + j;
-        uint32_t y[R];
-#pragma unroll
-        for (int rr = 0; rr < R; ++rr) y[rr] = lds[(rr * 16 + ka) * C + cl];
-        reg_ntt<MM, LAZY, LOGR, false>(y, a.roots, m);
-#pragma unroll
-        for (int kr = 0; kr < R; ++kr) {
-            const uint32_t row = (uint32_t)(ka + 16 * kr);
-            uint32_t v = y[kr];
-            if constexpr (!INVERSE) {
-                if (row != 0) v = O::mul_tw(v, tw[(size_t)row << a.logS], m);
-            }
-            const uint32_t idx = base + (row << a.logS);
-            if (idx < a.out_len) out[idx] = a.canon ? O::canon(v, m) : v;
-        }
-    }
+    col16_body<MM, LAZY, LOGR, INVERSE, HALF>(a, m, lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 template <class MM, bool LAZY, int LOGR>

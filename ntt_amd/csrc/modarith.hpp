@@ -131,7 +131,8 @@ NTT_HD uint32_t mulhi32(uint32_t a, uint32_t b)
 #endif
 }
 
-// x in [0, 2m) -> [0, m)
+// x in [0, 2m) -> [0, m).  (A v_sub_co_u32 + v_cndmask_b32 form was A/B-tested on MI355X and is
+// 3 % slower end to end than this v_sub_u32 + v_min_u32 form.)
 NTT_HD uint32_t csub(uint32_t x, uint32_t m)
 {
     uint32_t t = x - m;
