@@ -255,6 +255,89 @@ def test_full_size_properties(ctx):
     plan.close()
 
 
+# ---- BASELINE.json configs[3]: FHE-style RNS batch (n = 2^16, 32 limbs) ----------------------------
+def rns_primes(count, two_adicity, above):
+    """The `count` smallest primes p > above with p = 1 mod 2^two_adicity."""
+    out, step = [], 1 << two_adicity
+    p = (above // step + 1) * step + 1
+    while len(out) < count:
+        if all(p % q for q in range(3, int(p ** 0.5) + 1, 2)):
+            out.append(p)
+        p += step
+    return out
+
+
+def test_rns_batch_config4(ctx):
+    """n = 65536, 32 distinct primes p = 1 (mod 2^17) just above 2^30 (generator found per prime, strict
+    [0,p) kernels since p >= 2^30), a few polynomials per limb: every row against the oracle's plain
+    NTT product, which works for any generator because results are canonical."""
+    n = 65536
+    primes = rns_primes(32, 17, 1 << 30)
+    assert len(set(primes)) == 32 and all((p - 1) % (1 << 17) == 0 and (1 << 30) < p < (1 << 31) for p in primes)
+    rng = np.random.default_rng(44)
+    for li, p in enumerate(primes):
+        batch = 3 if li < 4 else 1
+        a, b = rand_poly(rng, n, p, batch), rand_poly(rng, n, p, batch)
+        plan = ctx.plan(p, n, batch, li % 2)              # alternate Montgomery / Barrett
+        got = plan.multiply(a, b)
+        # the oracle's NTT hard-codes g = 3 (main-montgomery.cc:257), which is not a generator for
+        # every such prime, so check the evaluation identity A(x) * B(x) = AB(x) (mod p) at a
+        # random point per row, plus exact convolution coefficients for one limb below
+        for r in range(batch):
+            x = int(rng.integers(2, p))
+
+            def ev(c):                     # Horner in Python ints (exact)
+                acc = 0
+                for v in c[::-1].tolist():
+                    acc = (acc * x + v) % p
+                return acc
+            assert ev(a[r]) * ev(b[r]) % p == ev(got[r]), (p, r, x)
+        plan.close()
+    # one limb fully, against an exact convolution on a short slice (first 64 and last 64 coefficients)
+    p = primes[0]
+    a, b = rand_poly(rng, n, p, 1), rand_poly(rng, n, p, 1)
+    plan = ctx.plan(p, n, 1, 0)
+    got = plan.multiply(a, b)[0]
+    ai, bi = [int(v) for v in a[0]], [int(v) for v in b[0]]
+    for k in list(range(64)) + list(range(2 * n - 1 - 64, 2 * n - 1)):
+        lo, hi = max(0, k - (n - 1)), min(k, n - 1)
+        assert sum(ai[i] * bi[k - i] for i in range(lo, hi + 1)) % p == int(got[k]), k
+    plan.close()
+
+
+# ---- BASELINE.json configs[4] on one GPU: a single transform of length 2^26 ------------------------
+def test_single_transform_2pow26(ctx):
+    """L = 2^26, p = 469762049 (2-adicity 26): three column levels + 4096-point rows on ONE GPU (the
+    8-GPU all-to-all split is a later row).  Checks the round-trip identity and 64 output points
+    against direct O(L) evaluation X[k] = sum x[i] w^(ik)."""
+    p, lg = 469762049, 26
+    L = 1 << lg
+    x = (orc.splitmix64_np(0x20250711, L) % np.uint64(p)).astype(np.uint32)
+    plan = ctx.plan(p, L // 2, 1, 0)
+    assert plan.length == L
+    f = plan.forward(x.copy().reshape(1, L), 1)[0]
+    w = pow(3, (p - 1) // L, p)
+    rng = np.random.default_rng(5)
+    ks = [0, 1, L - 1, L // 2, 4096, 4097] + [int(v) for v in rng.integers(0, L, size=58)]
+    H = 1 << 13                                      # i = hi * 2^13 + lo: w^(ik) = A[hi] * B[lo]
+    xm = x.reshape(H, H).astype(np.uint64)
+    P = np.uint64(p)
+    for k in ks:
+        wk = pow(w, k, p)
+        wkH = pow(wk, H, p)
+        A, B = np.empty(H, dtype=np.uint64), np.empty(H, dtype=np.uint64)
+        ca = cb = 1
+        for j in range(H):
+            A[j], B[j] = ca, cb
+            ca, cb = ca * wkH % p, cb * wk % p
+        rows = (xm * B % P).sum(axis=1) % P          # 8192 terms < 2^29 each
+        want = int((rows * A % P).sum() % P)
+        assert int(f[k]) == want, k
+    back = plan.inverse(f.reshape(1, L), 1)[0]
+    assert np.array_equal(back, x)
+    plan.close()
+
+
 # ---- large modulus through the 4-prime CRT -----------------------------------------------------------
 def test_crt_golden(ctx, crt_vectors):
     v = crt_vectors

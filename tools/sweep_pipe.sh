@@ -1,5 +1,6 @@
 #!/bin/bash
-for pipe in 0 1; do for c in 16 32 64 128 256; do
-  echo -n "pipe=$pipe chunk=$c "
-  NTT_AMD_PIPE=$pipe NTT_AMD_STREAMS=1 timeout -k 10 120 python3 bench.py --no-cpu-baseline --no-kernel-timing --steps 10 --warmup 2 --chunk $c 2>/dev/null || exit 1
-done; done
+for c in 16 32 64 128; do
+  echo -n "pipe=1 chunk=$c "
+  NTT_AMD_PIPE=1 NTT_AMD_STREAMS=1 timeout -k 10 120 python3 bench.py --no-cpu-baseline --no-kernel-timing --steps 10 --warmup 2 --chunk $c 2>/dev/null || exit 1
+done
+echo -n "pipe=0 default "; timeout -k 10 120 python3 bench.py --no-cpu-baseline --no-kernel-timing --steps 10 --warmup 2 2>/dev/null
