@@ -9,7 +9,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-export NTT_AMD_STREAMS=${NTT_AMD_STREAMS:-1}   # one lane: per-kernel durations are not overlapped
+# default lanes (NTT_AMD_STREAMS unset): the trace then sees the same overlapped launches as bench.py
 cd /tmp
 BENCH="python3 $REPO/bench.py --no-cpu-baseline"
 
