@@ -24,13 +24,23 @@ struct Ops {
     {
         return u - v + bound(m);
     }
+    // (u - v) mod bound-range: u - v wraps above 2^32 - bound when negative, so the unsigned
+    // minimum of d and d + bound picks the representative in [0, bound)  (3 instructions; the
+    // csub(sub_raw()) form costs 4)
     static __device__ __forceinline__ uint32_t sub(uint32_t u, uint32_t v, const ModParams &m)
     {
-        return csub(sub_raw(u, v, m), bound(m));
+        const uint32_t d = u - v, e = d + bound(m);
+        return e < d ? e : d;
     }
     static __device__ __forceinline__ uint32_t mul_tw(uint32_t x, tw_t w, const ModParams &m)
     {
         uint32_t r = MM::mul_tw(x, w, m);             // [0, 2p)
+        return LAZY ? r : csub(r, m.p);
+    }
+    // (u - v) * w for the nontrivial butterflies
+    static __device__ __forceinline__ uint32_t mul_tw_diff(uint32_t u, uint32_t v, tw_t w, const ModParams &m)
+    {
+        uint32_t r = MM::mul_tw_diff(u, v, w, bound(m), m);
         return LAZY ? r : csub(r, m.p);
     }
     static __device__ __forceinline__ uint32_t canon(uint32_t x, const ModParams &m)
@@ -95,8 +105,11 @@ __device__ __forceinline__ void reg_ntt(uint32_t (&x)[1 << LOGN], const Roots64<
                     x[blk + j + half] = O::sub_raw(u, v, m);
                 } else {
                     x[blk + j] = O::add(u, v, m);
-                    x[blk + j + half] = (j == 0) ? O::sub(u, v, m)
-                                                 : O::mul_tw(O::sub_raw(u, v, m), roots.w[j * step], m);
+                    // signed-mad form for <= 16 points (7 twiddle constants); the 32/64-point
+                    // register transforms would need 15/31 extra SGPR pairs and measured slower
+                    if (j == 0) x[blk + j + half] = O::sub(u, v, m);
+                    else if (LOGN <= 4) x[blk + j + half] = O::mul_tw_diff(u, v, roots.w[j * step], m);
+                    else x[blk + j + half] = O::mul_tw(O::sub_raw(u, v, m), roots.w[j * step], m);
                 }
             }
         }

@@ -156,6 +156,21 @@ struct Mont32 {
     {
         return redc_lazy((uint64_t)x * w, m);
     }
+    // (u - v + bound) * w mod p in [0, 2p) for u, v in [0, bound), bound <= 2^31: the "+ bound"
+    // rides in the 64-bit addend of a signed v_mad_i64_i32 (bound * w is wave-uniform), which
+    // saves the separate v_add_u32 of the sub_raw() form.
+    static NTT_HD uint32_t mul_tw_diff(uint32_t u, uint32_t v, tw_t w, uint32_t bound, const ModParams &m)
+    {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTT_NO_MADI64)
+        // hipcc expands a signed 32x32+64 C++ expression into five instructions; ask for the one
+        const uint64_t C = (uint64_t)bound * w;         // wave-uniform: scalar multiply
+        uint64_t T, carry;
+        asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(T), "=s"(carry) : "v"(u - v), "v"(w), "s"(C));
+        return redc_lazy(T, m);
+#else
+        return mul_tw(u - v + bound, w, m);
+#endif
+    }
     // a*b*R^-1 mod p in [0, 2p); a any u32, b < p (or a*b < 2^32 * p)
     static NTT_HD uint32_t mul_raw(uint32_t a, uint32_t b, const ModParams &m)
     {
@@ -175,6 +190,10 @@ struct Barrett32 {
     {
         uint32_t q = mulhi32(x, t.wq);
         return x * t.w - q * m.p;                      // exact mod 2^32, value in [0, 2p)
+    }
+    static NTT_HD uint32_t mul_tw_diff(uint32_t u, uint32_t v, tw_t t, uint32_t bound, const ModParams &m)
+    {
+        return mul_tw(u - v + bound, t, m);            // the quotient estimate needs the non-negative value
     }
     // Classic Barrett (HAC 14.42, base 2) for T = a*b with a, b < p < 2^k:
     // q = ((T >> (k-1)) * mu) >> (k+1) underestimates floor(T/p) by at most 2, so

@@ -3,6 +3,26 @@
 #pragma once
 #include "device_ntt.hpp"
 
+// Ablation switches for timing experiments (tools/ablate_row.sh); never defined in the shipped build:
+//   NTT_ABL_NODATA  row kernels take synthetic inputs instead of global loads and skip the store
+//   NTT_ABL_NOTW    4-step/row twiddles come from the SGPR root table instead of global loads
+//   NTT_ABL_NOLDS   the LDS exchanges (and their barriers) are skipped
+#if defined(NTT_ABL_NOTW)
+#define NTT_TW(tab, idx) a.roots.w[(idx) & 31]
+#else
+#define NTT_TW(tab, idx) (tab)[idx]
+#endif
+
+#if defined(NTT_ABL_NOLDS)
+#define NTT_LDS_ST(addr, v) asm volatile("" ::"v"(v))
+#define NTT_LDS_LD(dst, addr) asm volatile("" : "+v"(dst))
+#define NTT_BARRIER()
+#else
+#define NTT_LDS_ST(addr, v) lds[addr] = (v)
+#define NTT_LDS_LD(dst, addr) (dst) = lds[addr]
+#define NTT_BARRIER() __syncthreads()
+#endif
+
 namespace ntt {
 
 constexpr int kLdsWords = kRowLen + kRowLen / 16;      // 4352 dwords = 17 KiB
@@ -19,24 +39,24 @@ __device__ __forceinline__ void row_forward(uint32_t (&x)[16], uint32_t *lds, co
     reg_ntt<MM, LAZY, 4, false, true>(x, a.roots, m);            // loose: 15 of 16 outputs are multiplied next
     x[0] = O::tighten(x[0], m);
 #pragma unroll
-    for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], a.twA[k * 256 + t], m);
+    for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], NTT_TW(a.twA, k * 256 + t), m);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) lds[P1(k * 256 + t)] = x[k];
-    __syncthreads();
+    for (int k = 0; k < 16; ++k) NTT_LDS_ST(P1(k * 256 + t), x[k]);
+    NTT_BARRIER();
     const uint32_t b = t >> 4, i = t & 15;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) x[j] = lds[P1(b * 256 + j * 16 + i)];
-    __syncthreads();
+    for (int j = 0; j < 16; ++j) NTT_LDS_LD(x[j], P1(b * 256 + j * 16 + i));
+    NTT_BARRIER();
     reg_ntt<MM, LAZY, 4, false, true>(x, a.roots, m);
     x[0] = O::tighten(x[0], m);
 #pragma unroll
-    for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], a.twB[k * 16 + i], m);
+    for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], NTT_TW(a.twB, k * 16 + i), m);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) lds[P2(b * 256 + k * 16 + i)] = x[k];
-    __syncthreads();
+    for (int k = 0; k < 16; ++k) NTT_LDS_ST(P2(b * 256 + k * 16 + i), x[k]);
+    NTT_BARRIER();
 #pragma unroll
-    for (int j = 0; j < 16; ++j) x[j] = lds[P2(t * 16 + j)];
-    __syncthreads();
+    for (int j = 0; j < 16; ++j) NTT_LDS_LD(x[j], P2(t * 16 + j));
+    NTT_BARRIER();
     reg_ntt<MM, LAZY, 4, false>(x, a.roots, m);
 }
 
@@ -48,25 +68,25 @@ __device__ __forceinline__ void row_inverse(uint32_t (&x)[16], uint32_t *lds, co
     using O = Ops<MM, LAZY>;
     reg_ntt<MM, LAZY, 4, false, true>(x, a.iroots, m);           // loose values travel through LDS
 #pragma unroll
-    for (int j = 0; j < 16; ++j) lds[P2(t * 16 + j)] = x[j];
-    __syncthreads();
+    for (int j = 0; j < 16; ++j) NTT_LDS_ST(P2(t * 16 + j), x[j]);
+    NTT_BARRIER();
     const uint32_t b = t >> 4, i = t & 15;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = lds[P2(b * 256 + k * 16 + i)];
-    __syncthreads();
+    for (int k = 0; k < 16; ++k) NTT_LDS_LD(x[k], P2(b * 256 + k * 16 + i));
+    NTT_BARRIER();
     x[0] = O::tighten(x[0], m);
 #pragma unroll
-    for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], a.itwB[k * 16 + i], m);
+    for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], NTT_TW(a.itwB, k * 16 + i), m);
     reg_ntt<MM, LAZY, 4, false, true>(x, a.iroots, m);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) lds[P1(b * 256 + j * 16 + i)] = x[j];
-    __syncthreads();
+    for (int j = 0; j < 16; ++j) NTT_LDS_ST(P1(b * 256 + j * 16 + i), x[j]);
+    NTT_BARRIER();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = lds[P1(k * 256 + t)];
-    __syncthreads();
+    for (int k = 0; k < 16; ++k) NTT_LDS_LD(x[k], P1(k * 256 + t));
+    NTT_BARRIER();
     x[0] = O::tighten(x[0], m);
 #pragma unroll
-    for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], a.itwA[k * 256 + t], m);
+    for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], NTT_TW(a.itwA, k * 256 + t), m);
     // loose output: the innermost inverse column level multiplies every row (rows >= 1 by the
     // 4-step twiddle, row 0 by the scale constant), so no reduction is needed here
     reg_ntt<MM, LAZY, 4, false, true>(x, a.iroots, m);
@@ -83,18 +103,31 @@ __device__ __forceinline__ void row_mul_body(const RowArgs<MM> &a, const ModPara
     const uint32_t *__restrict__ pa = a.a + row;
     const uint32_t *__restrict__ pb = a.b + row;
     uint32_t xa[16], xb[16];
+#if defined(NTT_ABL_NODATA)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { xa[j] = t + j; xb[j] = t * 3 + j; }
+    (void)pa; (void)pb;
+#else
 #pragma unroll
     for (int j = 0; j < 16; ++j) xa[j] = pa[t + 256 * j];
 #pragma unroll
     for (int j = 0; j < 16; ++j) xb[j] = pb[t + 256 * j];
+#endif
     row_forward<MM, LAZY>(xa, lds, t, a, m);
     row_forward<MM, LAZY>(xb, lds, t, a, m);
 #pragma unroll
     for (int k = 0; k < 16; ++k) xa[k] = O::mul(xa[k], xb[k], m);
     row_inverse<MM, LAZY>(xa, lds, t, a, m);
     uint32_t *__restrict__ po = a.out + row;
+#if defined(NTT_ABL_NODATA)
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc ^= xa[j];
+    if (acc == 0x9e3779b9u) po[t] = acc;            // keeps the computation live, practically never stores
+#else
 #pragma unroll
     for (int j = 0; j < 16; ++j) po[t + 256 * j] = xa[j];
+#endif
 }
 
 }  // namespace ntt
