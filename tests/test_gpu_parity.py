@@ -365,6 +365,52 @@ def test_crt_vs_oracle_large(ctx):
     assert np.array_equal(ctx.crt_multiply(a, b, p64), want)
 
 
+# ---- the harness loop as a program: ntt_cli on the reference's text formats ---------------------------
+def test_cli_harness_loop(nt, nttdata, tmp_path):
+    """ntt_amd/ntt_cli = main() of main-montgomery.cc:298-362 on top of the C ABI: reads <id>.in, multiplies
+    on the GPU, checks against <id>.out, prints the reference's verdict and latency lines, writes files/<id>.out."""
+    import subprocess
+    data, out = tmp_path / "nttdata", tmp_path / "files"
+    data.mkdir()
+    out.mkdir()
+    for cid in (0, 1, 3):
+        n, p, a, b, ab = nttdata[cid]
+        with open(data / f"{cid}.in", "w") as f:          # the reference's layout (SURVEY section 4)
+            f.write(f"{n} {p}\n" + "".join(f"{v} " for v in a) + "\n" + "".join(f"{v} " for v in b))
+        with open(data / f"{cid}.out", "w") as f:
+            f.write("".join(f"{v} " for v in ab))
+    # a 51-bit case for the CRT branch (nttdata/4.* is not shipped: synthetic, expected from the oracle)
+    p64, n4 = 1337006139375617, 1000
+    rng = np.random.default_rng(4)
+    a4 = rng.integers(0, p64, size=n4, dtype=np.uint64)
+    b4 = rng.integers(0, p64, size=n4, dtype=np.uint64)
+    ab4, _ = orc.poly_multiply_crt(a4, b4, p64, threads=2)
+    with open(data / "4.in", "w") as f:
+        f.write(f"{n4} {p64}\n" + "".join(f"{v} " for v in a4) + "\n" + "".join(f"{v} " for v in b4))
+    with open(data / "4.out", "w") as f:
+        f.write("".join(f"{v} " for v in ab4))
+    exe = os.path.join(os.path.dirname(nt.__file__), "ntt_cli")
+    for extra in ([], ["--barrett"]):
+        r = subprocess.run([exe, "--data", str(data), "--out", str(out), "--begin", "0", "--end", "4",
+                            "--epochs", "3"] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.strip().split("\n")
+        assert lines.count("多项式乘法结果正确") == 4 and "多项式乘法结果错误" not in r.stdout
+        assert any(l.startswith("average latency for n = 131072 p = 469762049 : ") and l.endswith(" (us) ")
+                   for l in r.stdout.split("\n"))
+        assert "case 2 skipped" in r.stderr                 # missing file: reported, no spurious verdict
+        n, p, a, b, ab = nttdata[1]
+        got = np.loadtxt(out / "1.out", dtype=np.uint64)   # fWrite format: one value per line
+        assert np.array_equal(got.astype(np.uint32), ab)
+        assert np.array_equal(np.loadtxt(out / "4.out", dtype=np.uint64), ab4)
+    # a wrong expected file must flip the verdict and the exit status
+    with open(data / "0.out", "w") as f:
+        f.write("4 21 30 48 39 30 9 ")
+    r = subprocess.run([exe, "--data", str(data), "--out", str(out), "--begin", "0", "--end", "0", "--epochs", "1"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "多项式乘法结果错误" in r.stdout
+
+
 # ---- error behaviour -----------------------------------------------------------------------------------
 def test_errors(nt, ctx):
     with pytest.raises(nt.NttError) as e:

@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Secondary measurements for BASELINE.json configs[2..4] on ONE MI355X (bench.py stays the headline,
+configs[1]).  One JSON line per config; results are kept under profiles/.
+
+  config 3: large-modulus product through the 4-prime CRT, n = 2^17, p = 1337006139375617,
+            device-resident u64 in/out (ntt_crt_multiply: reduce, 4 residue products, Garner merge)
+  config 4: FHE-style RNS batch, n = 2^16, 32 primes = 1 (mod 2^17) above 2^30, 256 polynomial pairs
+            per limb (8192 products), device-resident
+  config 5: one forward + one inverse transform of length 2^26, p = 469762049 (natural order API)
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def rns_primes(count, two_adicity, above):
+    out, step = [], 1 << two_adicity
+    p = (above // step + 1) * step + 1
+    while len(out) < count:
+        if all(p % q for q in range(3, int(p ** 0.5) + 1, 2)):
+            out.append(p)
+        p += step
+    return out
+
+
+def main():
+    import torch
+    import ntt_amd
+    import orc
+
+    ctx = ntt_amd.Context(0)
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    # ---- config 3 ------------------------------------------------------------------------------
+    n, p64 = 131072, 1337006139375617
+    a = orc.splitmix64_np(0x20250711, n) % np.uint64(p64)
+    b = orc.splitmix64_np(0x20250711 + 1, n) % np.uint64(p64)
+    da = torch.from_numpy(a.view(np.int64)).cuda()
+    db = torch.from_numpy(b.view(np.int64)).cuda()
+    dab = torch.zeros(2 * n - 1, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        ctx.crt_multiply(da, db, p64, out=dab)
+    sync()
+    want, _ = orc.poly_multiply_crt(a, b, p64, threads=8)
+    assert np.array_equal(dab.cpu().numpy().view(np.uint64), want)
+    reps = 50
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.crt_multiply(da, db, p64, out=dab)
+    sync()
+    dt = (time.perf_counter() - t0) / reps
+    _, cpu_s = orc.poly_multiply_crt(a, b, p64, threads=min(16, os.cpu_count() or 1))
+    print(json.dumps({"config": "3: 4-prime CRT product, n=2^17, p=1337006139375617, one GPU, device-resident",
+                      "ms_per_product": dt * 1e3, "products_per_s": 1 / dt,
+                      "cpu_oracle_ms_per_product": cpu_s * 1e3,
+                      "reference_published_ms": 90.7393}), flush=True)
+
+    # ---- config 4 ------------------------------------------------------------------------------
+    n, limbs, per = 65536, 32, 256
+    primes = rns_primes(limbs, 17, 1 << 30)
+    plans = [ctx.plan(p, n, per, ntt_amd.MONTGOMERY) for p in primes]
+    rng = np.random.default_rng(1)
+    xa = torch.from_numpy(rng.integers(0, primes[0], size=(per, n), dtype=np.int64).astype(np.int32)).cuda()
+    xb = torch.from_numpy(rng.integers(0, primes[0], size=(per, n), dtype=np.int64).astype(np.int32)).cuda()
+    out = torch.zeros((per, 2 * n), dtype=torch.int32, device="cuda")
+
+    def rns_step():
+        for pl in plans:          # same buffers for every limb: values < the smallest prime are valid everywhere
+            pl.multiply(xa, xb, out=out, batch=per, out_stride=2 * n)
+
+    rns_step()
+    sync()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rns_step()
+    sync()
+    dt = (time.perf_counter() - t0) / reps
+    print(json.dumps({"config": "4: RNS batch n=2^16, 32 limbs x 256 pairs (strict [0,p) kernels, p > 2^30), one GPU",
+                      "ms_per_batch": dt * 1e3, "poly_mults_per_s": limbs * per / dt}), flush=True)
+    for pl in plans:
+        pl.close()
+
+    # ---- config 5 ------------------------------------------------------------------------------
+    p, L = 469762049, 1 << 26
+    x = torch.from_numpy((orc.splitmix64_np(7, L) % np.uint64(p)).astype(np.uint32).view(np.int32)).cuda()
+    plan = ctx.plan(p, L // 2, 1, ntt_amd.MONTGOMERY)
+    plan.forward(x, 1)
+    plan.inverse(x, 1)
+    sync()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        plan.forward(x, 1)
+        plan.inverse(x, 1)
+    sync()
+    dt = (time.perf_counter() - t0) / reps
+    print(json.dumps({"config": "5: forward + inverse transform, L=2^26, p=469762049, one GPU (natural order in/out)",
+                      "ms_per_roundtrip": dt * 1e3, "gbytes_algorithmic": 4 * L * 4 / 1e9,
+                      "algorithmic_GBps": 4 * L * 4 / dt / 1e9}), flush=True)
+    plan.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
