@@ -105,6 +105,23 @@ int ntt_inverse(ntt_plan *plan, uint32_t *data, int batch);
 int ntt_crt_multiply(ntt_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *ab, int n,
                      uint64_t p64);
 
+/* The two halves of ntt_crt_multiply as separate calls, for the prime-per-GPU sharding of the
+ * reference's MPI driver (main-mpi.cc:657-660 gives each rank ceil(4/size) primes, :770 runs
+ * process_mods_in_process on them, :772-796 gathers the residue polynomials and merges):
+ *   ntt_crt_prime(k, &m)            the k-th fixed prime (k = 0..3), main-openmp.cc:654
+ *   ntt_crt_residue_multiply        reduce a, b (< 2^64) mod prime k and multiply: res[0..2n-2] in [0, m_k)
+ *                                   (CRT_parallel, main-openmp.cc:424-440)
+ *   ntt_crt_merge                   out[i] = CRT(r0[i], r1[i], r2[i], r3[i]) mod p64 for `count`
+ *                                   coefficients -- any slice of the product, so that every rank can
+ *                                   merge its own slice after an all-to-all
+ *                                   (CRT_combine_parallel, main-openmp.cc:468-485)
+ * Host or device pointers. */
+int ntt_crt_prime(int index, uint32_t *p);
+int ntt_crt_residue_multiply(ntt_ctx *ctx, const uint64_t *a, const uint64_t *b, uint32_t *res, int n,
+                             int prime_index);
+int ntt_crt_merge(ntt_ctx *ctx, const uint32_t *r0, const uint32_t *r1, const uint32_t *r2,
+                  const uint32_t *r3, uint64_t *out, size_t count, uint64_t p64);
+
 /* Per-kernel timing (HIP events on the context's stream) for bench.py's roofline block.
  * With timing enabled every kernel launch is bracketed by events; ntt_ctx_kernel_time returns
  * the accumulated milliseconds and launch count of kernel `index` (0 .. count-1) and its name;

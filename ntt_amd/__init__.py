@@ -36,7 +36,8 @@ MONTGOMERY, BARRETT = 0, 1
 EXPORTED_SYMBOLS = (
     "poly_multiply", "ntt_ctx_create", "ntt_ctx_destroy", "ntt_ctx_set_stream", "ntt_ctx_stream",
     "ntt_ctx_synchronize", "ntt_plan_create", "ntt_plan_destroy", "ntt_plan_length",
-    "ntt_poly_multiply_batched", "ntt_forward", "ntt_inverse", "ntt_crt_multiply",
+    "ntt_poly_multiply_batched", "ntt_forward", "ntt_inverse", "ntt_crt_multiply", "ntt_crt_prime",
+    "ntt_crt_residue_multiply", "ntt_crt_merge",
     "ntt_ctx_enable_kernel_timing", "ntt_ctx_kernel_time", "ntt_last_error", "ntt_read_case",
     "ntt_check_case", "ntt_write_case",
 )
@@ -70,6 +71,9 @@ def _load():
     lib.ntt_forward.argtypes = [vp, vp, i32]
     lib.ntt_inverse.argtypes = [vp, vp, i32]
     lib.ntt_crt_multiply.argtypes = [vp, vp, vp, vp, i32, u64]
+    lib.ntt_crt_prime.argtypes = [i32, C.POINTER(u32)]
+    lib.ntt_crt_residue_multiply.argtypes = [vp, vp, vp, vp, i32, i32]
+    lib.ntt_crt_merge.argtypes = [vp, vp, vp, vp, vp, vp, sz, u64]
     lib.ntt_ctx_enable_kernel_timing.argtypes = [vp, i32]
     lib.ntt_ctx_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                         C.POINTER(C.c_long)]
@@ -140,6 +144,25 @@ class Context:
                                      _ptr(out, np.uint64), n, int(p64)))
         return out
 
+    def crt_residue_multiply(self, a, b, prime_index, out=None):
+        """Residue product mod the k-th CRT prime (CRT_parallel, main-openmp.cc:424-440): uint32[2n-1]."""
+        n = int(a.shape[-1])
+        if out is None:
+            out = np.zeros(2 * n - 1, dtype=np.uint32)
+        _check(_lib.ntt_crt_residue_multiply(self._h, _ptr(a, np.uint64), _ptr(b, np.uint64),
+                                             _ptr(out, np.uint32), n, int(prime_index)))
+        return out
+
+    def crt_merge(self, rows, p64, out=None, count=None):
+        """CRT_combine_parallel (main-openmp.cc:468-485) on any slice: rows = four uint32 arrays."""
+        if count is None:
+            count = int(rows[0].shape[-1])
+        if out is None:
+            out = np.zeros(count, dtype=np.uint64)
+        _check(_lib.ntt_crt_merge(self._h, *[_ptr(r, np.uint32) for r in rows], _ptr(out, np.uint64),
+                                  count, int(p64)))
+        return out
+
     def enable_kernel_timing(self, enable=True):
         _check(_lib.ntt_ctx_enable_kernel_timing(self._h, 1 if enable else 0))
 
@@ -197,6 +220,12 @@ class Plan:
     def inverse(self, data, batch=1):
         _check(_lib.ntt_inverse(self._h, _ptr(data, np.uint32), batch))
         return data
+
+
+def crt_prime(index):
+    p = C.c_uint32()
+    _check(_lib.ntt_crt_prime(index, C.byref(p)))
+    return p.value
 
 
 def poly_multiply(a, b, p):

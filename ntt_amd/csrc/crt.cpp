@@ -32,7 +32,7 @@ void crt_release(ntt_ctx *ctx)
         pl = nullptr;
     }
     w.ra.release(); w.rb.release(); w.res.release();
-    w.a64.release(); w.b64.release(); w.out64.release();
+    w.a64.release(); w.b64.release(); w.out64.release(); w.merge_in.release();
     w.n = 0;
 }
 
@@ -134,6 +134,127 @@ extern "C" int ntt_crt_multiply(ntt_ctx *ctx, const uint64_t *a, const uint64_t 
         HIP_TRY(hipMemcpyAsync(ab, dout, out_len * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     } else if (!dev_a || !dev_b) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return NTT_OK;
+}
+
+// ---- the two halves of the CRT path as separate entry points (prime-per-GPU sharding) --------------
+static int crt_check(ntt_ctx *ctx, int n, uint64_t p64, bool need_p64)
+{
+    if (!ctx) return fail(NTT_ERR_INVALID, "null context");
+    if (n <= 0) return fail(NTT_ERR_INVALID, "n must be positive");
+    if (n > (1 << 22)) return fail(NTT_ERR_UNSUPPORTED, "n too large for the 2^23-adic prime 998244353");
+    if (need_p64 && ((p64 & 1) == 0 || p64 < 3 || p64 >= (1ULL << 62)))
+        return fail(NTT_ERR_UNSUPPORTED, "p64 must be odd and below 2^62");
+    return NTT_OK;
+}
+
+static int crt_plans(ntt_ctx *ctx, int n)
+{
+    CrtWorkspace &w = ctx->crt;
+    if (w.n == n) return NTT_OK;
+    crt_release(ctx);
+    for (int k = 0; k < 4; ++k) {
+        int rc = ntt_plan_create(ctx, kCrtMods[k], n, 1, NTT_MODMUL_MONTGOMERY, &w.plans[k]);
+        if (rc) { crt_release(ctx); return rc; }
+    }
+    w.n = n;
+    return NTT_OK;
+}
+
+extern "C" int ntt_crt_prime(int index, uint32_t *p)
+{
+    if (index < 0 || index >= 4 || !p) return fail(NTT_ERR_INVALID, "ntt_crt_prime: index must be 0..3");
+    *p = kCrtMods[index];
+    return NTT_OK;
+}
+
+extern "C" int ntt_crt_residue_multiply(ntt_ctx *ctx, const uint64_t *a, const uint64_t *b, uint32_t *res,
+                                        int n, int prime_index)
+{
+    int rc = crt_check(ctx, n, 0, false);
+    if (rc) return rc;
+    if (!a || !b || !res || prime_index < 0 || prime_index >= 4)
+        return fail(NTT_ERR_INVALID, "ntt_crt_residue_multiply: bad argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    if ((rc = crt_plans(ctx, n))) return rc;
+    CrtWorkspace &w = ctx->crt;
+    const size_t N = (size_t)n, out_len = 2 * N - 1;
+    if ((rc = w.ra.ensure(4 * N * 4)) || (rc = w.rb.ensure(4 * N * 4)) || (rc = w.res.ensure(4 * out_len * 4))) return rc;
+    const uint64_t *da = a, *db = b;
+    const bool dev_a = is_device_ptr(a), dev_b = is_device_ptr(b), dev_o = is_device_ptr(res);
+    if (!dev_a) {
+        if ((rc = w.a64.ensure(N * 8))) return rc;
+        HIP_TRY(hipMemcpyAsync(w.a64.ptr, a, N * 8, hipMemcpyHostToDevice, ctx->stream));
+        da = static_cast<const uint64_t *>(w.a64.ptr);
+    }
+    if (!dev_b) {
+        if ((rc = w.b64.ensure(N * 8))) return rc;
+        HIP_TRY(hipMemcpyAsync(w.b64.ptr, b, N * 8, hipMemcpyHostToDevice, ctx->stream));
+        db = static_cast<const uint64_t *>(w.b64.ptr);
+    }
+    CrtConsts cc{};
+    make_consts(3, cc);                                    // only the per-prime constants are used here
+    const int k = prime_index;
+    uint32_t *ra = static_cast<uint32_t *>(w.ra.ptr) + k * N, *rb = static_cast<uint32_t *>(w.rb.ptr) + k * N;
+    uint32_t *dres = dev_o ? res : static_cast<uint32_t *>(w.res.ptr) + k * out_len;
+    ctx->begin(K_CRT_REDUCE);
+    launch_crt_reduce(da, ra, N, cc.prime[k], ctx->stream);
+    launch_crt_reduce(db, rb, N, cc.prime[k], ctx->stream);
+    ctx->end();
+    if ((rc = multiply_device_any(w.plans[k], ra, rb, dres, out_len, 1))) return rc;
+    HIP_TRY(hipGetLastError());
+    if (!dev_o) {
+        HIP_TRY(hipMemcpyAsync(res, dres, out_len * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    } else if (!dev_a || !dev_b) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return NTT_OK;
+}
+
+extern "C" int ntt_crt_merge(ntt_ctx *ctx, const uint32_t *r0, const uint32_t *r1, const uint32_t *r2,
+                             const uint32_t *r3, uint64_t *out, size_t count, uint64_t p64)
+{
+    int rc = crt_check(ctx, 1, p64, true);
+    if (rc) return rc;
+    if (!r0 || !r1 || !r2 || !r3 || !out || count == 0) return fail(NTT_ERR_INVALID, "ntt_crt_merge: bad argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    CrtWorkspace &w = ctx->crt;
+    const uint32_t *src[4] = {r0, r1, r2, r3};
+    const uint32_t *rows[4];
+    bool any_host = false;
+    for (int k = 0; k < 4; ++k) any_host = any_host || !is_device_ptr(src[k]);
+    if (any_host) {
+        if ((rc = w.merge_in.ensure(4 * count * 4))) return rc;
+        for (int k = 0; k < 4; ++k) {
+            uint32_t *d = static_cast<uint32_t *>(w.merge_in.ptr) + k * count;
+            HIP_TRY(hipMemcpyAsync(d, src[k], count * 4, is_device_ptr(src[k]) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                   ctx->stream));
+            rows[k] = d;
+        }
+    } else {
+        for (int k = 0; k < 4; ++k) rows[k] = src[k];
+    }
+    const bool dev_o = is_device_ptr(out);
+    uint64_t *dout = out;
+    if (!dev_o) {
+        if ((rc = w.out64.ensure(count * 8))) return rc;
+        dout = static_cast<uint64_t *>(w.out64.ptr);
+    }
+    CrtConsts cc{};
+    make_consts(p64, cc);
+    ctx->begin(K_CRT_MERGE);
+    launch_crt_merge(rows, dout, count, cc, ctx->stream);
+    ctx->end();
+    HIP_TRY(hipGetLastError());
+    if (!dev_o) {
+        HIP_TRY(hipMemcpyAsync(out, dout, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    } else if (any_host) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     return NTT_OK;

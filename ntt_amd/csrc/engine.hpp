@@ -34,7 +34,7 @@ struct DeviceBuffer {
 struct CrtWorkspace {
     int n = 0;
     ntt_plan *plans[4] = {nullptr, nullptr, nullptr, nullptr};
-    DeviceBuffer ra, rb, res, a64, b64, out64;
+    DeviceBuffer ra, rb, res, a64, b64, out64, merge_in;
 };
 void crt_release(ntt_ctx *ctx);
 const char *last_error_cstr();

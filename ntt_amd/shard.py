@@ -72,3 +72,48 @@ class Group:
         if self.dist is not None:
             self.dist.destroy_process_group()
             self.dist = None
+
+
+def crt_multiply_sharded(group, residue_fn, merge_fn, n, device="cpu"):
+    """Large-modulus product with the four CRT primes sharded over the ranks of `group`
+    (main-mpi.cc:657-660: rank r owns primes partition(4, world, r)) and the ONE exchange step the
+    path has: instead of the reference's gather-to-root (main-mpi.cc:772-791, after which rank 0
+    alone merges, :793-796) every rank receives coefficient slice r of all four residue polynomials
+    (all-to-all over RCCL/xGMI, 4 B per coefficient and prime), merges its slice, and the u64 slices
+    are all-gathered.
+
+    residue_fn(k) -> int32 torch tensor [2n-1] (u32 bit pattern) with the product mod prime k;
+    merge_fn(rows, count) -> int64 torch tensor [count] from four int32 tensors [count].
+    Returns an int64 torch tensor [2n-1] (u64 bit pattern), identical on every rank.
+    The callbacks must hand back tensors whose producing work is complete with respect to torch's
+    current stream (the library runs on its own stream: synchronise the context, or give it torch's
+    stream with Context.set_stream).
+    """
+    import torch
+    world, rank = group.world, group.rank
+    out_len = 2 * n - 1
+    sl = -(-out_len // world)                       # coefficients per rank (last slices zero padded)
+    maxk = -(-4 // world)                           # primes per rank, main-mpi.cc:657
+    start, count = partition(4, world, rank)
+    send = torch.zeros((world, maxk, sl), dtype=torch.int32, device=device)
+    for j in range(count):
+        r = residue_fn(start + j)
+        padded = torch.zeros(world * sl, dtype=torch.int32, device=device)
+        padded[:out_len] = r
+        send[:, j, :] = padded.view(world, sl)
+    if world > 1:
+        recv = torch.empty_like(send)
+        group.dist.all_to_all_single(recv.view(-1), send.view(-1))
+    else:
+        recv = send
+    rows = []
+    for k in range(4):                              # prime k came from rank k // maxk, slot k % maxk
+        rows.append(recv[k // maxk, k % maxk, :].contiguous())
+    mine = merge_fn(rows, sl)
+    if world > 1:
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        group.dist.all_gather(parts, mine)
+        full = torch.cat(parts)
+    else:
+        full = mine
+    return full[:out_len]

@@ -44,3 +44,20 @@ def test_two_ranks_gloo(tmp_path):
         a = (orc.splitmix64_np(0x20250711 + u, n) % np.uint64(p)).astype(np.uint32)
         b = (orc.splitmix64_np(0x20250711 + (1 << 20) + u, n) % np.uint64(p)).astype(np.uint32)
         assert res["sums"][str(u)] == int(orc.poly_multiply(a, b, p).astype(np.uint64).sum())
+
+
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_crt_sharded_gloo(tmp_path, world):
+    """Prime-per-rank CRT with the all-to-all exchange, 2 and 3 ranks (3: one rank owns
+    no prime, as in main-mpi.cc:657-660 with size = 3)."""
+    out = tmp_path / "crt.txt"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29540 + world),
+           os.path.join(HERE, "_gloo_crt_worker.py"), str(out)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert out.read_text() == "ok"

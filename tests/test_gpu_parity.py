@@ -365,6 +365,47 @@ def test_crt_vs_oracle_large(ctx):
     assert np.array_equal(ctx.crt_multiply(a, b, p64), want)
 
 
+def test_crt_sharded_world1(nt, ctx):
+    """The prime-per-GPU CRT driver (ntt_amd.shard.crt_multiply_sharded) fed by the real C-ABI halves
+    ntt_crt_residue_multiply / ntt_crt_merge, world_size 1 (the exchange itself is covered by the gloo
+    tests on CPU); also the halves on host pointers against the golden residues."""
+    import torch
+    from ntt_amd import shard
+    assert [nt.crt_prime(k) for k in range(4)] == list(orc.CRT_MODS)
+    p64, n = 1337006139375617, 5000
+    rng = np.random.default_rng(8)
+    a = rng.integers(0, p64, size=n, dtype=np.uint64)
+    b = rng.integers(0, p64, size=n, dtype=np.uint64)
+    want, res, _ = orc.poly_multiply_crt(a, b, p64, threads=4, want_residues=True)
+    rows = [ctx.crt_residue_multiply(a, b, k) for k in range(4)]           # host pointers
+    for k in range(4):
+        assert np.array_equal(rows[k], res[k, :2 * n - 1].astype(np.uint32)), k
+    assert np.array_equal(ctx.crt_merge(rows, p64), want)
+    assert np.array_equal(ctx.crt_merge([r[100:200].copy() for r in rows], p64), want[100:200])   # any slice
+    da = torch.from_numpy(a.view(np.int64)).cuda()
+    db = torch.from_numpy(b.view(np.int64)).cuda()
+
+    # the library works on its own stream: order it against torch's stream on both sides of each call
+    def residue_fn(k):
+        out = torch.zeros(2 * n - 1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.crt_residue_multiply(da, db, k, out=out)
+        ctx.synchronize()
+        return out
+
+    def merge_fn(r4, count):
+        out = torch.zeros(count, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        ctx.crt_merge(r4, p64, out=out, count=count)
+        ctx.synchronize()
+        return out
+
+    g = shard.Group("nccl", device=torch.device("cuda", 0))       # WORLD_SIZE unset: no process group
+    got = shard.crt_multiply_sharded(g, residue_fn, merge_fn, n, device="cuda")
+    ctx.synchronize()
+    assert np.array_equal(got.cpu().numpy().view(np.uint64), want)
+
+
 # ---- the harness loop as a program: ntt_cli on the reference's text formats ---------------------------
 def test_cli_harness_loop(nt, nttdata, tmp_path):
     """ntt_amd/ntt_cli = main() of main-montgomery.cc:298-362 on top of the C ABI: reads <id>.in, multiplies
