@@ -295,12 +295,7 @@ static int multiply_pipelined(ntt_plan *pl, const uint32_t *a, const uint32_t *b
                                 L, out_len, pl->tw_inv[0], true, pl->scale_mul, true);
             pa.groups_i = cb_of(t - 2) * per;
         }
-        static const int dbg_mask = std::getenv("NTT_AMD_PIPE_MASK") ? std::atoi(std::getenv("NTT_AMD_PIPE_MASK")) : 7;
-        if (!(dbg_mask & 1)) pa.groups_f = 0;      // timing experiments only: results are wrong
-        if (!(dbg_mask & 2)) pa.groups_r = 0;
-        if (!(dbg_mask & 4)) pa.groups_i = 0;
         const unsigned groups = std::max(pa.groups_f, std::max(pa.groups_r, pa.groups_i));
-        if (groups == 0) continue;
         cx->begin(K_PIPE);
         launch_pipe(pl->kind, pl->lazy, pl->level_log[0], &pa, pl->mp, groups, cx->cur);
         cx->end();

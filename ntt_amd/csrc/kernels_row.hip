@@ -13,8 +13,6 @@
 // row_mul_kernel fuses: forward(a row), forward(b row), pointwise product
 // (main-montgomery.cc:341-344) and the inverse row transform -- the 12 small-stride stages of
 // three NTT_iterative calls plus the pointwise loop in one read of a, b and one write.
-#include <cstdlib>
-
 #include "row_body.hpp"
 
 namespace ntt {
@@ -67,10 +65,7 @@ __global__ void __launch_bounds__(256) row_inv_kernel(const RowArgs<MM> a, const
 template <int WHICH, class MM, bool LAZY>
 static void launch_row_t(const RowArgs<MM> &a, const ModParams &mp, unsigned rows, hipStream_t s)
 {
-    // NTT_AMD_ROW_DYNLDS (bytes of unused dynamic LDS) lowers the row kernel's occupancy for
-    // timing experiments (17 KiB static + this, per workgroup of 4 waves).
-    static const unsigned dyn = std::getenv("NTT_AMD_ROW_DYNLDS") ? (unsigned)std::atoi(std::getenv("NTT_AMD_ROW_DYNLDS")) : 0u;
-    if (WHICH == 0) hipLaunchKernelGGL((row_mul_kernel<MM, LAZY>), dim3(rows), dim3(256), dyn, s, a, mp);
+    if (WHICH == 0) hipLaunchKernelGGL((row_mul_kernel<MM, LAZY>), dim3(rows), dim3(256), 0, s, a, mp);
     if (WHICH == 1) hipLaunchKernelGGL((row_fwd_kernel<MM, LAZY>), dim3(rows), dim3(256), 0, s, a, mp);
     if (WHICH == 2) hipLaunchKernelGGL((row_inv_kernel<MM, LAZY>), dim3(rows), dim3(256), 0, s, a, mp);
 }

@@ -41,6 +41,21 @@ def main():
         ctx.synchronize()
         torch.cuda.synchronize()
 
+    # ---- headline workload with HOST buffers across the boundary (PCIe-inclusive; never bench.py's value)
+    n, p, B = 131072, 998244353, 256
+    ha = (orc.splitmix64_np(1, B * n) % np.uint64(p)).astype(np.uint32).reshape(B, n)
+    hb = (orc.splitmix64_np(2, B * n) % np.uint64(p)).astype(np.uint32).reshape(B, n)
+    hab = np.zeros((B, 2 * n - 1), dtype=np.uint32)
+    plan = ctx.plan(p, n, B, ntt_amd.MONTGOMERY)
+    plan.multiply(ha, hb, out=hab)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        plan.multiply(ha, hb, out=hab)
+    dt = (time.perf_counter() - t0) / 3
+    print(json.dumps({"config": "1 with pageable HOST buffers handed over the C ABI (H2D a, b + D2H ab inside the call)",
+                      "batch": B, "poly_mults_per_s": B / dt, "GBps_over_pcie": B * (16 * n - 4) / dt / 1e9}), flush=True)
+    plan.close()
+
     # ---- config 3 ------------------------------------------------------------------------------
     n, p64 = 131072, 1337006139375617
     a = orc.splitmix64_np(0x20250711, n) % np.uint64(p64)
