@@ -82,7 +82,8 @@ int ntt_plan_destroy(ntt_plan *plan);
 int ntt_plan_length(const ntt_plan *plan);
 
 /* batch products: a, b are [batch][n] u32 (row stride n), ab is [batch][2n-1] stored with row
- * stride `ab_stride` elements (>= 2n-1; SURVEY 8d uses 2n).  Host or device pointers.
+ * stride `ab_stride` elements (>= 2n-1; SURVEY 8d uses 2n); batch <= the plan's batch capacity.
+ * Host or device pointers.
  * Replaces the harness multiply body main-montgomery.cc:326-351 / main-barrett.cc:258-282
  * (pad, NTT, NTT, pointwise, inverse NTT, copy 2n-1). */
 int ntt_poly_multiply_batched(ntt_plan *plan, const uint32_t *a, const uint32_t *b, uint32_t *ab,

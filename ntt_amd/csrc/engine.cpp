@@ -689,6 +689,7 @@ int ntt_poly_multiply_batched(ntt_plan *pl, const uint32_t *a, const uint32_t *b
 {
     if (!pl || !a || !b || !ab) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched: null argument");
     if (batch <= 0) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched: batch must be positive");
+    if (batch > pl->batch) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched: batch exceeds the plan's capacity");
     const size_t n = (size_t)pl->n, out_len = 2 * n - 1;
     if (ab_stride < out_len) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched: ab_stride < 2n-1");
     ntt_ctx *cx = pl->ctx;
@@ -733,6 +734,7 @@ static int transform_entry(ntt_plan *pl, uint32_t *data, int batch, bool inverse
 {
     if (!pl || !data) return fail(NTT_ERR_INVALID, "ntt_forward/inverse: null argument");
     if (batch <= 0) return fail(NTT_ERR_INVALID, "ntt_forward/inverse: batch must be positive");
+    if (batch > pl->batch) return fail(NTT_ERR_INVALID, "ntt_forward/inverse: batch exceeds the plan's capacity");
     ntt_ctx *cx = pl->ctx;
     std::lock_guard<std::mutex> lk(cx->mu);
     HIP_TRY(hipSetDevice(cx->device));

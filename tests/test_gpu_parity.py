@@ -108,6 +108,44 @@ def test_multiply_vs_oracle(ctx, n, kind):
         plan.close()
 
 
+def test_randomised_shapes_and_primes(ctx):
+    """Seeded sweep over (prime, n, batch, kind, stride): ragged n around every path boundary
+    (L = 4096 | 8192, column levels 1 | 2), NTT primes of different 2-adicity and size, odd strides."""
+    rng = np.random.default_rng(20250711)
+    # 2013265921 = 15 * 2^27 + 1 has smallest generator 31, not the reference's hard-coded 3: the
+    # oracle's g = 3 transform is not valid there, so that prime is checked by evaluation instead
+    primes = [7340033, 104857601, 469762049, 998244353, 1004535809, 1224736769, 2013265921, 167772161, 40961]
+    ns = [1, 2, 6, 17, 129, 1023, 1025, 2047, 2048, 2049, 3000, 4095, 4097, 6000, 8191, 8193, 12345, 16385,
+          33000, 70000, 131071, 131073, 262145]
+    for trial in range(60):
+        p = int(primes[rng.integers(len(primes))])
+        n = int(ns[rng.integers(len(ns))])
+        L = 1 << max(1, (2 * n - 1).bit_length())
+        if (p - 1) % L:
+            continue
+        batch = int(rng.integers(1, 4)) if n < 40000 else 1
+        kind = int(rng.integers(2))
+        stride = 2 * n - 1 + int(rng.integers(0, 3))
+        a, b = rand_poly(rng, n, p, batch), rand_poly(rng, n, p, batch)
+        plan = ctx.plan(p, n, batch, kind)
+        got = plan.multiply(a, b, out=np.full((batch, stride), 0xABCDEF01, dtype=np.uint32), out_stride=stride)
+        for r in range(batch):
+            if p == 2013265921:
+                x = int(rng.integers(2, p))
+
+                def ev(c):
+                    acc = 0
+                    for v in c[::-1].tolist():
+                        acc = (acc * x + v) % p
+                    return acc
+                assert ev(a[r]) * ev(b[r]) % p == ev(got[r, :2 * n - 1]), (p, n, r, kind)
+                assert got[r, :2 * n - 1].max() < p
+            else:
+                assert np.array_equal(got[r, :2 * n - 1], orc.poly_multiply(a[r], b[r], p, kind="barrett")), (p, n, r, kind)
+        assert np.all(got[:, 2 * n - 1:] == 0xABCDEF01), (p, n)
+        plan.close()
+
+
 def test_multi_level_columns(ctx):
     # L = 2^19 and 2^20: two column levels in front of the 4096-point rows
     rng = np.random.default_rng(5)
@@ -466,6 +504,8 @@ def test_errors(nt, ctx):
     plan = ctx.plan(998244353, 16, 1)
     with pytest.raises(nt.NttError):
         plan.multiply(np.zeros((1, 16), np.uint32), np.zeros((1, 16), np.uint32), out_stride=10)
+    with pytest.raises(nt.NttError):               # more products than the plan was sized for
+        plan.multiply(np.zeros((2, 16), np.uint32), np.zeros((2, 16), np.uint32))
     plan.close()
 
 
