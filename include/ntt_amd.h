@@ -123,6 +123,26 @@ int ntt_crt_residue_multiply(ntt_ctx *ctx, const uint64_t *a, const uint64_t *b,
 int ntt_crt_merge(ntt_ctx *ctx, const uint32_t *r0, const uint32_t *r1, const uint32_t *r2,
                   const uint32_t *r3, uint64_t *out, size_t count, uint64_t p64);
 
+/* One transform of length L = 2^lgL split over `world` GPUs (one process each), the pieces a rank
+ * runs between the two all-to-all exchanges (BASELINE.json configs[4]; the reference has nothing
+ * like it: its transforms live in static arrays of 300000, main-montgomery.cc:297).  Rank r holds
+ * x[r*S .. (r+1)*S), S = L/world.  Forward:
+ *   all-to-all #1 (rank r sends its elements with i2 in piece h to rank h; the receiver holds the
+ *                  [world][S/world] array x[i1][i2 in its piece])
+ *   ntt_dist_colpass(plan, data, 0)   world-point NTT over i1, times w_L^(i2*k1), canonical, in place
+ *   all-to-all #2 (row k1 goes to rank k1, which now holds the full row Y[k1][0..S))
+ *   ntt_dist_local(plan, row, 0)      S-point forward transform, natural order
+ * after which rank k1 holds X[k1 + world*k2], k2 = 0..S-1.  The inverse runs the same steps
+ * backwards with inverse = 1 (scaled by L^-1 in total).  Device pointers only for the column pass.
+ * ntt_amd/shard.py::dist_transform drives the exchanges with torch.distributed (RCCL). */
+typedef struct ntt_dist_plan ntt_dist_plan;
+int ntt_dist_plan_create(ntt_ctx *ctx, uint32_t p, int lgL, int world, int rank, int modmul_kind,
+                         ntt_dist_plan **out_plan);
+int ntt_dist_plan_destroy(ntt_dist_plan *plan);
+int ntt_dist_colpass(ntt_dist_plan *plan, uint32_t *data, int inverse);
+int ntt_dist_local(ntt_dist_plan *plan, uint32_t *row, int inverse);
+int ntt_dist_local_length(const ntt_dist_plan *plan);
+
 /* Per-kernel timing (HIP events on the context's stream) for bench.py's roofline block.
  * With timing enabled every kernel launch is bracketed by events; ntt_ctx_kernel_time returns
  * the accumulated milliseconds and launch count of kernel `index` (0 .. count-1) and its name;

@@ -37,7 +37,8 @@ EXPORTED_SYMBOLS = (
     "poly_multiply", "ntt_ctx_create", "ntt_ctx_destroy", "ntt_ctx_set_stream", "ntt_ctx_stream",
     "ntt_ctx_synchronize", "ntt_plan_create", "ntt_plan_destroy", "ntt_plan_length",
     "ntt_poly_multiply_batched", "ntt_forward", "ntt_inverse", "ntt_crt_multiply", "ntt_crt_prime",
-    "ntt_crt_residue_multiply", "ntt_crt_merge",
+    "ntt_crt_residue_multiply", "ntt_crt_merge", "ntt_dist_plan_create", "ntt_dist_plan_destroy",
+    "ntt_dist_colpass", "ntt_dist_local", "ntt_dist_local_length",
     "ntt_ctx_enable_kernel_timing", "ntt_ctx_kernel_time", "ntt_last_error", "ntt_read_case",
     "ntt_check_case", "ntt_write_case",
 )
@@ -74,6 +75,11 @@ def _load():
     lib.ntt_crt_prime.argtypes = [i32, C.POINTER(u32)]
     lib.ntt_crt_residue_multiply.argtypes = [vp, vp, vp, vp, i32, i32]
     lib.ntt_crt_merge.argtypes = [vp, vp, vp, vp, vp, vp, sz, u64]
+    lib.ntt_dist_plan_create.argtypes = [vp, u32, i32, i32, i32, i32, C.POINTER(vp)]
+    lib.ntt_dist_plan_destroy.argtypes = [vp]
+    lib.ntt_dist_colpass.argtypes = [vp, vp, i32]
+    lib.ntt_dist_local.argtypes = [vp, vp, i32]
+    lib.ntt_dist_local_length.argtypes = [vp]
     lib.ntt_ctx_enable_kernel_timing.argtypes = [vp, i32]
     lib.ntt_ctx_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                         C.POINTER(C.c_long)]
@@ -220,6 +226,38 @@ class Plan:
     def inverse(self, data, batch=1):
         _check(_lib.ntt_inverse(self._h, _ptr(data, np.uint32), batch))
         return data
+
+
+class DistPlan:
+    """This rank's pieces of one length-2^lgL transform split over `world` GPUs (``ntt_dist_plan``)."""
+
+    def __init__(self, ctx, p, lgL, world, rank, kind=MONTGOMERY):
+        h = C.c_void_p()
+        _check(_lib.ntt_dist_plan_create(ctx._h, int(p), int(lgL), int(world), int(rank), int(kind), C.byref(h)))
+        self._h = h
+        self.ctx, self.p, self.lgL, self.world, self.rank = ctx, int(p), int(lgL), int(world), int(rank)
+        self.local_length = _lib.ntt_dist_local_length(h)
+
+    def close(self):
+        if self._h:
+            _lib.ntt_dist_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def colpass(self, data, inverse=False):
+        """In place on the [world][S/world] device array held after the first all-to-all."""
+        _check(_lib.ntt_dist_colpass(self._h, _ptr(data, np.uint32), 1 if inverse else 0))
+        return data
+
+    def local(self, row, inverse=False):
+        """S-point transform (natural order) of this rank's row, in place."""
+        _check(_lib.ntt_dist_local(self._h, _ptr(row, np.uint32), 1 if inverse else 0))
+        return row
 
 
 def crt_prime(index):

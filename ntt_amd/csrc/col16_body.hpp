@@ -74,6 +74,7 @@ __device__ __forceinline__ void col16_body(const ColArgs<MM> &a, const ModParams
             uint32_t v = y[kr];
             if constexpr (!INVERSE) {
                 v = row != 0 ? O::mul_tw(v, tw[(size_t)row << a.logS], m) : O::tighten(v, m);
+                if (a.canon) v = O::canon(v, m);
             } else {
                 // non-final levels hand loose values to the next level; the final one canonicalises
                 if (a.canon) v = O::canon(O::tighten(v, m), m);

@@ -762,3 +762,149 @@ int ntt_forward(ntt_plan *plan, uint32_t *data, int batch) { return transform_en
 int ntt_inverse(ntt_plan *plan, uint32_t *data, int batch) { return transform_entry(plan, data, batch, true); }
 
 }  // extern "C"
+
+// ================================================================================================
+// Distributed single transform: the pieces one rank runs between the all-to-alls
+// ================================================================================================
+namespace ntt {
+
+template <class MM>
+static int build_dist_tables(ntt_dist_plan *dp, uint32_t p, uint32_t g)
+{
+    ntt_plan *pl = dp->colp;
+    const ModParams &mp = pl->mp;
+    const uint64_t L = 1ULL << dp->lgL;
+    const uint32_t G = (uint32_t)dp->world, cols = dp->S / G, off = (uint32_t)dp->rank * cols;
+    const uint32_t wL = h_powmod(g, (p - 1) / L, p), iwL = h_powmod(wL, p - 2, p);
+    const uint32_t invG = h_powmod(G % p, p - 2, p);
+    dp->scale = bytes_of_tw<MM>(invG, mp);
+    Roots64<MM> r{}, ir{};
+    const uint32_t w64 = h_powmod(wL, L / 64, p), iw64 = h_powmod(iwL, L / 64, p);
+    uint32_t c = 1, ic = 1;
+    for (int j = 0; j < 32; ++j) {
+        r.w[j] = MM::make_tw(c, mp);
+        ir.w[j] = MM::make_tw(ic, mp);
+        c = h_mulmod(c, w64, p);
+        ic = h_mulmod(ic, iw64, p);
+    }
+    pl->roots.assign((unsigned char *)&r, (unsigned char *)&r + sizeof(r));
+    pl->iroots.assign((unsigned char *)&ir, (unsigned char *)&ir + sizeof(ir));
+    if (pl->level_log[0] >= 5) {
+        const uint32_t wN = h_powmod(wL, L / G, p), iwN = h_powmod(iwL, L / G, p);
+        typename MM::tw_t f[64], b[64];
+        for (uint32_t rr = 0; rr < 4; ++rr)
+            for (uint32_t ka = 0; ka < 16; ++ka) {
+                f[rr * 16 + ka] = MM::make_tw(h_powmod(wN, (uint64_t)rr * ka, p), mp);
+                b[rr * 16 + ka] = MM::make_tw(h_powmod(iwN, (uint64_t)rr * ka, p), mp);
+            }
+        pl->tw_in_fwd[0].assign((unsigned char *)f, (unsigned char *)f + sizeof(f));
+        pl->tw_in_inv[0].assign((unsigned char *)b, (unsigned char *)b + sizeof(b));
+    }
+    // tw[k1][j] = w_L^((off + j) * k1); the inverse table carries world^-1
+    std::vector<typename MM::tw_t> tf((size_t)G * cols), ti((size_t)G * cols);
+    for (uint32_t k1 = 0; k1 < G; ++k1) {
+        const uint32_t wk = h_powmod(wL, k1, p), iwk = h_powmod(iwL, k1, p);
+        uint32_t cur = h_powmod(wk, off, p), icur = h_mulmod(h_powmod(iwk, off, p), invG, p);
+        for (uint32_t j = 0; j < cols; ++j) {
+            tf[(size_t)k1 * cols + j] = MM::make_tw(cur, mp);
+            ti[(size_t)k1 * cols + j] = MM::make_tw(icur, mp);
+            cur = h_mulmod(cur, wk, p);
+            icur = h_mulmod(icur, iwk, p);
+        }
+    }
+    int rc = upload_table<MM>(pl, tf, &pl->tw_fwd[0]);
+    if (rc) return rc;
+    return upload_table<MM>(pl, ti, &pl->tw_inv[0]);
+}
+
+}  // namespace ntt
+
+extern "C" {
+
+int ntt_dist_plan_destroy(ntt_dist_plan *dp)
+{
+    if (!dp) return NTT_OK;
+    if (dp->local) ntt_plan_destroy(dp->local);
+    if (dp->colp) ntt_plan_destroy(dp->colp);
+    delete dp;
+    return NTT_OK;
+}
+
+int ntt_dist_plan_create(ntt_ctx *ctx, uint32_t p, int lgL, int world, int rank, int modmul_kind,
+                         ntt_dist_plan **out)
+{
+    if (!ctx || !out) return fail(NTT_ERR_INVALID, "ntt_dist_plan_create: null argument");
+    *out = nullptr;
+    if (world < 2 || world > 64 || (world & (world - 1)) || rank < 0 || rank >= world)
+        return fail(NTT_ERR_INVALID, "ntt_dist_plan_create: world must be a power of two in 2..64, 0 <= rank < world");
+    int lgG = 0;
+    while ((1 << lgG) < world) ++lgG;
+    if (lgL > 30 || lgL < 8 + 2 * lgG)
+        return fail(NTT_ERR_UNSUPPORTED, "ntt_dist_plan_create: need 256 * world^2 <= L <= 2^30");
+    if (p >= (1u << 31) || p < 3 || !h_is_prime(p) || ((uint64_t)(p - 1) % (1ULL << lgL)) != 0)
+        return fail(NTT_ERR_UNSUPPORTED, "ntt_dist_plan_create: p must be a prime < 2^31 with 2^lgL | p - 1");
+    if (modmul_kind != NTT_MODMUL_MONTGOMERY && modmul_kind != NTT_MODMUL_BARRETT)
+        return fail(NTT_ERR_INVALID, "ntt_dist_plan_create: unknown modmul_kind");
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::unique_ptr<ntt_dist_plan> dp(new ntt_dist_plan());
+    dp->ctx = ctx;
+    dp->lgL = lgL;
+    dp->world = world;
+    dp->rank = rank;
+    dp->S = 1u << (lgL - lgG);
+    // local S-point transforms: same generator, so its root w_S equals w_L^world
+    int rc = ntt_plan_create(ctx, p, (int)(dp->S / 2), 1, modmul_kind, &dp->local);
+    if (rc) return rc;
+    ntt_plan *cp = new ntt_plan();
+    dp->colp = cp;
+    cp->ctx = ctx;
+    cp->p = p;
+    cp->g = dp->local->g;
+    cp->n = (int)(dp->S / 2);
+    cp->logL = lgL - lgG;                 // the column pass sees one block = the whole local array
+    cp->L = dp->S;
+    cp->batch = 1;
+    cp->kind = modmul_kind;
+    cp->mp = dp->local->mp;
+    cp->lazy = dp->local->lazy;
+    cp->nlevels = 1;
+    cp->level_log[0] = lgG;
+    cp->level_logM[0] = lgL - lgG;
+    cp->col16_fwd = cp->col16_inv = lgG >= 5;
+    rc = modmul_kind == NTT_MODMUL_MONTGOMERY ? build_dist_tables<Mont32>(dp.get(), p, cp->g)
+                                              : build_dist_tables<Barrett32>(dp.get(), p, cp->g);
+    if (rc) { ntt_dist_plan_destroy(dp.release()); return rc; }
+    *out = dp.release();
+    return NTT_OK;
+}
+
+int ntt_dist_colpass(ntt_dist_plan *dp, uint32_t *data, int inverse)
+{
+    if (!dp || !data) return fail(NTT_ERR_INVALID, "ntt_dist_colpass: null argument");
+    ntt_ctx *cx = dp->ctx;
+    std::lock_guard<std::mutex> lk(cx->mu);
+    HIP_TRY(hipSetDevice(cx->device));
+    if (!is_device_ptr(data)) return fail(NTT_ERR_INVALID, "ntt_dist_colpass: data must be a device pointer");
+    ntt_plan *pl = dp->colp;
+    cx->cur = cx->stream;
+    const uint32_t S = dp->S;
+    const bool inv = inverse != 0;
+    if (pl->kind == NTT_MODMUL_MONTGOMERY)
+        col_pass<Mont32>(pl, 0, inv, false, data, nullptr, data, nullptr, S, S, S, S,
+                         inv ? pl->tw_inv[0] : pl->tw_fwd[0], inv, dp->scale, true, 1, 1);
+    else
+        col_pass<Barrett32>(pl, 0, inv, false, data, nullptr, data, nullptr, S, S, S, S,
+                            inv ? pl->tw_inv[0] : pl->tw_fwd[0], inv, dp->scale, true, 1, 1);
+    HIP_TRY(hipGetLastError());
+    return NTT_OK;
+}
+
+int ntt_dist_local(ntt_dist_plan *dp, uint32_t *row, int inverse)
+{
+    if (!dp) return fail(NTT_ERR_INVALID, "ntt_dist_local: null argument");
+    return inverse ? ntt_inverse(dp->local, row, 1) : ntt_forward(dp->local, row, 1);
+}
+
+int ntt_dist_local_length(const ntt_dist_plan *dp) { return dp ? (int)dp->S : 0; }
+
+}  // extern "C"

@@ -108,3 +108,16 @@ struct ntt_plan {
     ntt::DeviceBuffer work0, work1;
     std::vector<void *> owned;          // device allocations to free
 };
+
+// Distributed transform of length L = 2^lgL over `world` ranks (include/ntt_amd.h, ntt_dist_*):
+// `local` transforms this rank's S = L/world points, `colp` is a one-level column-pass plan over the
+// [world][S/world] array a rank holds after the first all-to-all, with this rank's slice of the
+// 4-step twiddles w_L^(i2*k1).
+struct ntt_dist_plan {
+    ntt_ctx *ctx = nullptr;
+    ntt_plan *local = nullptr;
+    ntt_plan *colp = nullptr;
+    int lgL = 0, world = 1, rank = 0;
+    uint32_t S = 0;
+    std::vector<unsigned char> scale;      // world^-1 (inverse column pass, row 0)
+};

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) col_kernel(const ColArgs<MM> a, const Mod
         const uint32_t idx = base + ((uint32_t)k1 << a.logS);
         // inverse: non-final levels hand loose values to the next level; the final one canonicalises
         uint32_t v = x[k1];
-        if (INVERSE && a.canon) v = O::canon(O::tighten(v, m), m);
+        if (a.canon) v = O::canon(INVERSE ? O::tighten(v, m) : v, m);
         if (idx < a.out_len) out[idx] = v;
     }
 }

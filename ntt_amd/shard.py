@@ -117,3 +117,40 @@ def crt_multiply_sharded(group, residue_fn, merge_fn, n, device="cpu"):
     else:
         full = mine
     return full[:out_len]
+
+
+def dist_transform(world, rank, all_to_all, colpass_fn, local_fn, x_local, inverse=False):
+    """One transform of length L = world * S split over `world` ranks (BASELINE.json configs[4]).
+
+    Forward: rank r holds x[r*S:(r+1)*S] (natural order) and ends with X[r + world*k2], k2 < S.
+    Inverse: the reverse (input in that transposed layout, output natural blocks, scaled by 1/L).
+    Two all-to-all exchanges, each moving (world-1)/world of the data, around the per-rank compute:
+      colpass_fn(arr2d [world][S/world], inverse) -> same shape   (ntt_dist_colpass on GPU boxes)
+      local_fn(row [S], inverse) -> [S]                           (ntt_dist_local)
+    all_to_all(send [world][S/world]) -> recv [world][S/world] with recv[s] = what rank s sent to us
+    (torch.distributed.all_to_all_single under the hood; injected so that tests can simulate ranks).
+    """
+    S = x_local.shape[0]
+    cols = S // world
+    if not inverse:
+        held = all_to_all(x_local.reshape(world, cols))      # held[i1][j] = x[i1*S + rank*cols + j]
+        held = colpass_fn(held, False)                       # held[k1][j] = Y[k1][rank*cols + j]
+        row = all_to_all(held).reshape(S)                    # row[h*cols + j] = Y[rank][h*cols + j]
+        return local_fn(row, False)
+    row = local_fn(x_local, True)                            # D[rank][i2], i2 natural
+    held = all_to_all(row.reshape(world, cols))              # held[k1][j] = D[k1][rank*cols + j]
+    held = colpass_fn(held, True)                            # held[i1][j] = x[i1*S + rank*cols + j]
+    return all_to_all(held).reshape(S)                       # x[rank*S + h*cols + j]
+
+
+def torch_all_to_all(group):
+    """all_to_all callable for dist_transform over a Group (RCCL on GPU tensors, gloo on CPU tensors)."""
+    def a2a(send):
+        import torch
+        send = send.contiguous()
+        if group.dist is None:
+            return send
+        recv = torch.empty_like(send)
+        group.dist.all_to_all_single(recv.view(-1), send.view(-1))
+        return recv
+    return a2a

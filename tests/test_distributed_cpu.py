@@ -61,3 +61,17 @@ def test_crt_sharded_gloo(tmp_path, world):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     assert out.read_text() == "ok"
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_dist_transform_gloo(tmp_path, world):
+    """One transform split over 2 / 4 ranks with two all-to-all exchanges, forward
+    and inverse, against the oracle's full-length transform."""
+    out = tmp_path / "dist.txt"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29550 + world),
+           os.path.join(HERE, "_gloo_dist_worker.py"), str(out)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert out.read_text() == "ok"

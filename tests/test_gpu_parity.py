@@ -344,7 +344,7 @@ def test_rns_batch_config4(ctx):
 
 
 # ---- BASELINE.json configs[4] on one GPU: a single transform of length 2^26 ------------------------
-def test_single_transform_2pow26(ctx):
+def test_single_transform_2pow26(nt, ctx):
     """L = 2^26, p = 469762049 (2-adicity 26): three column levels + 4096-point rows on ONE GPU (the
     8-GPU all-to-all split is a later row).  Checks the round-trip identity and 64 output points
     against direct O(L) evaluation X[k] = sum x[i] w^(ik)."""
@@ -371,6 +371,30 @@ def test_single_transform_2pow26(ctx):
         rows = (xm * B % P).sum(axis=1) % P          # 8192 terms < 2^29 each
         want = int((rows * A % P).sum() % P)
         assert int(f[k]) == want, k
+    # the same transform through the 8-rank decomposition of BASELINE configs[4] (virtual ranks in this
+    # process, exchanges by tensor shuffles): rank r must end with X[r + 8*k2]
+    import torch
+    G = 8
+    S, cols = L // G, L // G // G
+    dplans = [nt.DistPlan(ctx, p, lg, G, r, 0) for r in range(G)]
+    dx = torch.from_numpy(x.view(np.int32)).cuda()
+    held = [torch.stack([dx[s * S + d * cols: s * S + (d + 1) * cols] for s in range(G)]).contiguous() for d in range(G)]
+    del dx
+    torch.cuda.synchronize()
+    for r in range(G):
+        dplans[r].colpass(held[r], False)
+    ctx.synchronize()
+    rows = [torch.cat([held[s][d] for s in range(G)]).contiguous() for d in range(G)]
+    del held
+    torch.cuda.synchronize()
+    for r in range(G):
+        dplans[r].local(rows[r], False)
+    ctx.synchronize()
+    for r in range(G):
+        assert np.array_equal(rows[r].cpu().numpy().view(np.uint32), f[r::G]), r
+    for dp in dplans:
+        dp.close()
+    del rows
     back = plan.inverse(f.reshape(1, L), 1)[0]
     assert np.array_equal(back, x)
     plan.close()
@@ -442,6 +466,56 @@ def test_crt_sharded_world1(nt, ctx):
     got = shard.crt_multiply_sharded(g, residue_fn, merge_fn, n, device="cuda")
     ctx.synchronize()
     assert np.array_equal(got.cpu().numpy().view(np.uint64), want)
+
+
+def test_dist_transform_virtual_ranks(nt, ctx):
+    """The per-rank GPU pieces of the distributed transform (ntt_dist_colpass / ntt_dist_local) for
+    every rank of a virtual world in ONE process: the two all-to-all exchanges are done by tensor
+    shuffles here (their RCCL form is ntt_amd.shard.dist_transform, covered over gloo on CPU).
+    world = 8 is BASELINE configs[4]'s node size; 32 exercises the LDS-staged column kernel."""
+    import torch
+    for p, lgL, G, kind in ((469762049, 18, 8, 0), (998244353, 16, 4, 1), (469762049, 18, 32, 0),
+                            (1224736769, 17, 2, 0)):
+        L = 1 << lgL
+        S, cols = L // G, L // G // G
+        x = (orc.splitmix64_np(lgL * 100 + G, L) % np.uint64(p)).astype(np.uint32)
+        X = orc.ntt(x, p)
+        plans = [nt.DistPlan(ctx, p, lgL, G, r, kind) for r in range(G)]
+        assert plans[0].local_length == S
+
+        def a2a(sends):           # sends[s][d] goes to rank d; rank d holds stack over s
+            return [torch.stack([sends[s][d] for s in range(G)]).contiguous() for d in range(G)]
+
+        dx = torch.from_numpy(x.view(np.int32)).cuda()
+        held = a2a([dx[r * S:(r + 1) * S].reshape(G, cols) for r in range(G)])
+        torch.cuda.synchronize()
+        for r in range(G):
+            plans[r].colpass(held[r], False)
+        ctx.synchronize()
+        rows = [h.reshape(S).contiguous() for h in a2a(held)]
+        torch.cuda.synchronize()
+        for r in range(G):
+            plans[r].local(rows[r], False)
+        ctx.synchronize()
+        for r in range(G):
+            assert np.array_equal(rows[r].cpu().numpy().view(np.uint32), X[r::G]), (p, lgL, G, r)
+        # inverse from the transposed layout back to natural blocks
+        for r in range(G):
+            plans[r].local(rows[r], True)
+        ctx.synchronize()
+        held = a2a([rows[r].reshape(G, cols) for r in range(G)])
+        torch.cuda.synchronize()
+        for r in range(G):
+            plans[r].colpass(held[r], True)
+        ctx.synchronize()
+        back = torch.cat([h.reshape(S) for h in a2a(held)])
+        assert np.array_equal(back.cpu().numpy().view(np.uint32), x), (p, lgL, G)
+        for pl in plans:
+            pl.close()
+    with pytest.raises(nt.NttError):
+        nt.DistPlan(ctx, 998244353, 12, 8, 0)      # L < 256 * world^2
+    with pytest.raises(nt.NttError):
+        nt.DistPlan(ctx, 998244353, 20, 6, 0)      # world not a power of two
 
 
 # ---- the harness loop as a program: ntt_cli on the reference's text formats ---------------------------
