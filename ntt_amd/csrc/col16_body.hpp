@@ -1,6 +1,8 @@
 // col16_body.hpp -- device body of the LDS-staged column pass (see kernels_col16.hip), shared by the
 // stand-alone kernel and the fused pipeline kernel (kernels_pipe.hip).
 #pragma once
+#include <type_traits>
+
 #include "device_ntt.hpp"
 
 namespace ntt {
@@ -24,9 +26,13 @@ __device__ __forceinline__ void col16_body(const ColArgs<MM> &a, const ModParams
     const uint32_t S = 1u << a.logS;
     const uint32_t i2 = c & (S - 1);
     const uint32_t base = ((c >> a.logS) << a.logM) + i2;          // blk * M + i2
-        const uint32_t *__restrict__ in = a.in[op] + (size_t)by * a.in_stride;
-    uint32_t *__restrict__ out = a.out[op] + (size_t)by * a.out_stride;
-    const tw_t *__restrict__ tw = a.tw + i2;
+    // descriptors of this batch row: the range check gives zero padding (in_len) and the output cut
+    const bufrsrc_t rin = make_buf(a.in[op] + (size_t)by * a.in_stride, a.in_len * 4u);
+    const bufrsrc_t rout = make_buf(a.out[op] + (size_t)by * a.out_stride, a.out_len * 4u);
+    const bufrsrc_t rtw = make_buf(a.tw, (uint32_t)sizeof(tw_t) << a.logM);
+    const uint32_t voff = base * 4u;
+    const uint32_t twoff = i2 * (uint32_t)sizeof(tw_t);
+    const int rowsh = a.logS + 2, twsh = a.logS + tw_shift<tw_t>();
 
     // ---- pass 1: rows R*a + r ----------------------------------------------------------------
     uint32_t x[16];
@@ -35,13 +41,12 @@ __device__ __forceinline__ void col16_body(const ColArgs<MM> &a, const ModParams
         if (HALF && j >= 8) {
             x[j] = 0;
         } else {
-            const uint32_t row = (uint32_t)(R * j + r);
-            const uint32_t idx = base + (row << a.logS);
-            uint32_t v = idx < a.in_len ? in[idx] : 0u;
+            const uint32_t row = (uint32_t)(R * j + r);                // wave-uniform
+            uint32_t v = buf_load(rin, voff + (row << rowsh), 0);
             if constexpr (INVERSE) {
                 // inputs may be loose: every row is multiplied, except row 0 of an outer level
                 if (row == 0) v = a.use_scale0 ? O::mul_tw(v, a.scale0, m) : O::tighten(v, m);
-                else v = O::mul_tw(v, tw[(size_t)row << a.logS], m);
+                else v = O::mul_tw(v, buf_load_tw<tw_t>(rtw, twoff, row << twsh), m);
             }
             x[j] = v;
         }
@@ -60,29 +65,35 @@ __device__ __forceinline__ void col16_body(const ColArgs<MM> &a, const ModParams
     __syncthreads();
 
     // ---- pass 2: radix-R over r for ka in [q*KA, (q+1)*KA) ---------------------------------------
+    // non-final inverse levels hand loose values to the next level; a final pass canonicalises
+    // (a.canon is uniform: a branch around the whole pass, not a select per value); stores beyond
+    // out_len are dropped by the range check
     const int q = r;
+    auto pass2 = [&](auto canon_tag) {
+        constexpr bool CANON = decltype(canon_tag)::value;
 #pragma unroll
-    for (int j = 0; j < KA; ++j) {
-        const int ka = q * KA + j;
-        uint32_t y[R];
+        for (int j = 0; j < KA; ++j) {
+            const int ka = q * KA + j;
+            uint32_t y[R];
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) y[rr] = lds[(rr * 16 + ka) * C + cl];
-        reg_ntt<MM, LAZY, LOGR, false, true>(y, a.roots, m);      // loose outputs
+            for (int rr = 0; rr < R; ++rr) y[rr] = lds[(rr * 16 + ka) * C + cl];
+            reg_ntt<MM, LAZY, LOGR, false, true>(y, a.roots, m);  // loose outputs
 #pragma unroll
-        for (int kr = 0; kr < R; ++kr) {
-            const uint32_t row = (uint32_t)(ka + 16 * kr);
-            uint32_t v = y[kr];
-            if constexpr (!INVERSE) {
-                v = row != 0 ? O::mul_tw(v, tw[(size_t)row << a.logS], m) : O::tighten(v, m);
-                if (a.canon) v = O::canon(v, m);
-            } else {
-                // non-final levels hand loose values to the next level; the final one canonicalises
-                if (a.canon) v = O::canon(O::tighten(v, m), m);
+            for (int kr = 0; kr < R; ++kr) {
+                const uint32_t row = (uint32_t)(ka + 16 * kr);         // wave-uniform
+                uint32_t v = y[kr];
+                if constexpr (!INVERSE) {
+                    v = row != 0 ? O::mul_tw(v, buf_load_tw<tw_t>(rtw, twoff, row << twsh), m) : O::tighten(v, m);
+                    if constexpr (CANON) v = O::canon(v, m);
+                } else {
+                    if constexpr (CANON) v = O::canon(O::tighten(v, m), m);
+                }
+                buf_store(v, rout, voff + (row << rowsh), 0);
             }
-            const uint32_t idx = base + (row << a.logS);
-            if (idx < a.out_len) out[idx] = v;
         }
-    }
+    };
+    if (a.canon) pass2(std::true_type{});
+    else pass2(std::false_type{});
 }
 
 

@@ -65,6 +65,46 @@ struct Ops {
     }
 };
 
+// ---- buffer addressing ---------------------------------------------------------------------------
+// The column kernels read and write rows that are S elements apart.  Through a buffer descriptor
+// (base + size in four SGPRs) a row is reached with a 32-bit per-lane byte offset plus a scalar
+// offset, so an access costs at most one 32-bit add instead of a 64-bit address computation, and the
+// hardware range check (offset + 4 > size: loads return 0, stores are dropped) replaces the
+// explicit index guards that implement zero padding and the 2n-1 output cut.  Anything the range
+// check must see goes into the per-lane offset; the scalar offset is used only where every access
+// is in range by construction.
+using bufrsrc_t = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ bufrsrc_t make_buf(const void *base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint32_t buf_load(bufrsrc_t r, uint32_t voff, uint32_t soff)
+{
+    return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void buf_store(uint32_t v, bufrsrc_t r, uint32_t voff, uint32_t soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, 0);
+}
+// twiddle table entry (4 B Montgomery, 8 B Barrett)
+template <class TW>
+__device__ __forceinline__ TW buf_load_tw(bufrsrc_t r, uint32_t voff, uint32_t soff)
+{
+    if constexpr (sizeof(TW) == 4) {
+        return TW(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+    } else {
+        static_assert(sizeof(TW) == 8, "twiddle entries are 4 or 8 bytes");
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+        TW t;
+        t.w = v[0];
+        t.wq = v[1];
+        return t;
+    }
+}
+template <class TW>
+constexpr int tw_shift() { return sizeof(TW) == 4 ? 2 : 3; }
+
 __host__ __device__ constexpr int bitrev_c(int x, int bits)
 {
     int r = 0;

@@ -20,45 +20,51 @@ template <class MM, bool LAZY, int LOGN1, bool INVERSE, bool HALF>
 __global__ void __launch_bounds__(256) col_kernel(const ColArgs<MM> a, const ModParams m)
 {
     using O = Ops<MM, LAZY>;
+    using tw_t = typename MM::tw_t;
     constexpr int N1 = 1 << LOGN1;
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;          // column id within the row
     const uint32_t S = 1u << a.logS;
     const uint32_t i2 = c & (S - 1);
     const uint32_t base = ((c >> a.logS) << a.logM) + i2;        // blk * M + i2
     const int op = blockIdx.z;
-    const uint32_t *__restrict__ in = a.in[op] + (size_t)blockIdx.y * a.in_stride;
-    uint32_t *__restrict__ out = a.out[op] + (size_t)blockIdx.y * a.out_stride;
-    const typename MM::tw_t *__restrict__ tw = a.tw + i2;
+    // descriptors of this batch row: the range check gives zero padding (in_len) and the output cut
+    const bufrsrc_t rin = make_buf(a.in[op] + (size_t)blockIdx.y * a.in_stride, a.in_len * 4u);
+    const bufrsrc_t rout = make_buf(a.out[op] + (size_t)blockIdx.y * a.out_stride, a.out_len * 4u);
+    const bufrsrc_t rtw = make_buf(a.tw, (uint32_t)sizeof(tw_t) << a.logM);
+    const uint32_t voff = base * 4u;
+    const uint32_t twoff = i2 * (uint32_t)sizeof(tw_t);
+    const int rowsh = a.logS + 2, twsh = a.logS + tw_shift<tw_t>();
 
     uint32_t x[N1];
 #pragma unroll
     for (int i1 = 0; i1 < N1; ++i1) {
-        if (HALF && i1 >= N1 / 2) {
-            x[i1] = 0;
-        } else {
-            const uint32_t idx = base + ((uint32_t)i1 << a.logS);
-            x[i1] = idx < a.in_len ? in[idx] : 0u;
-        }
+        if (HALF && i1 >= N1 / 2) x[i1] = 0;
+        else x[i1] = buf_load(rin, voff + ((uint32_t)i1 << rowsh), 0);
     }
     if constexpr (INVERSE) {
         // inputs may be loose: every row is multiplied, except row 0 of an outer level
         x[0] = a.use_scale0 ? O::mul_tw(x[0], a.scale0, m) : O::tighten(x[0], m);
 #pragma unroll
-        for (int k1 = 1; k1 < N1; ++k1) x[k1] = O::mul_tw(x[k1], tw[(size_t)k1 << a.logS], m);
+        for (int k1 = 1; k1 < N1; ++k1)
+            x[k1] = O::mul_tw(x[k1], buf_load_tw<tw_t>(rtw, twoff, (uint32_t)k1 << twsh), m);
     }
     reg_ntt<MM, LAZY, LOGN1, HALF, true>(x, a.roots, m);          // loose outputs
     if constexpr (!INVERSE) {
         x[0] = O::tighten(x[0], m);
 #pragma unroll
-        for (int k1 = 1; k1 < N1; ++k1) x[k1] = O::mul_tw(x[k1], tw[(size_t)k1 << a.logS], m);
+        for (int k1 = 1; k1 < N1; ++k1)
+            x[k1] = O::mul_tw(x[k1], buf_load_tw<tw_t>(rtw, twoff, (uint32_t)k1 << twsh), m);
     }
+    // inverse: non-final levels hand loose values to the next level; the final one canonicalises.
+    // Stores beyond out_len are dropped by the range check.  (a.canon is uniform: a branch, not a
+    // select per value.)
+    if (a.canon) {
 #pragma unroll
-    for (int k1 = 0; k1 < N1; ++k1) {
-        const uint32_t idx = base + ((uint32_t)k1 << a.logS);
-        // inverse: non-final levels hand loose values to the next level; the final one canonicalises
-        uint32_t v = x[k1];
-        if (a.canon) v = O::canon(INVERSE ? O::tighten(v, m) : v, m);
-        if (idx < a.out_len) out[idx] = v;
+        for (int k1 = 0; k1 < N1; ++k1)
+            buf_store(O::canon(INVERSE ? O::tighten(x[k1], m) : x[k1], m), rout, voff + ((uint32_t)k1 << rowsh), 0);
+    } else {
+#pragma unroll
+        for (int k1 = 0; k1 < N1; ++k1) buf_store(x[k1], rout, voff + ((uint32_t)k1 << rowsh), 0);
     }
 }
 
