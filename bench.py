@@ -58,8 +58,8 @@ def cpu_baseline(n, p, threads, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--n", type=int, default=131072)
     ap.add_argument("--p", type=int, default=998244353)

@@ -653,11 +653,13 @@ int ntt_plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind,
         }
         pl->nlevels = m;
         // work buffers: two operands per product, `chunk` products per launch and per lane.
-        // Measured (profiles/sweep_chunk_r01.txt): throughput rises with the chunk up to ~128
-        // products (fewer launches, smaller tail rounds) and is insensitive to whether the
-        // intermediates fit the 256 MiB Infinity Cache, so the default is 128 MiB per lane (64 products at L = 2^18, the best of tools/sweep_final.sh).
+        // Measured (profiles/sweep_chunk_r01.txt, profiles/sweep_chunk_r01d.txt): throughput rises
+        // with the chunk up to ~40 products (fewer launches, smaller tail rounds), is flat from 40
+        // to 56 and drops 5 % at 64 and beyond, where the intermediates of the two lanes no longer
+        // fit the 256 MiB Infinity Cache together: the default is 96 MiB per lane (48 products at
+        // L = 2^18).
         size_t per = (size_t)L * sizeof(uint32_t);
-        long chunk = (long)((128u << 20) / (2 * per));
+        long chunk = (long)((96u << 20) / (2 * per));
         if (const char *e = std::getenv("NTT_AMD_CHUNK")) chunk = std::atol(e);
         chunk = std::max<long>(1, std::min<long>(chunk, batch));
         chunk = std::min<long>(chunk, 65535);
