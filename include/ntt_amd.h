@@ -106,6 +106,20 @@ int ntt_inverse(ntt_plan *plan, uint32_t *data, int batch);
 int ntt_crt_multiply(ntt_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *ab, int n,
                      uint64_t p64);
 
+/* Direct 64-bit path: products modulo ONE NTT-friendly prime p64 < 2^62 ((p64 - 1) divisible by
+ * L = 2^ceil(log2 2n)) with 64-bit Montgomery lanes (R = 2^64): a, b are [batch][n] u64 with values
+ * < p64, ab is [batch][2n-1] canonical residues with row stride ab_stride; host or device pointers.
+ * Replaces the single-modulus branch of main-openmp.cc:678-692 (`montgomery m(R = 2^60, p_)`,
+ * :650-651: toMontgomery, NTT_iterative x2, pointwise ModMul, inverse, fromMontgomery), which the
+ * reference only takes for p_ < 2^50; with 64-bit lanes it also serves the 51-bit modulus of the
+ * reference's fifth case, i.e. the caller of ntt_crt_multiply, for a prime of this shape. */
+typedef struct ntt_plan64 ntt_plan64;
+int ntt_plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, ntt_plan64 **out);
+int ntt_plan64_destroy(ntt_plan64 *plan);
+int ntt_plan64_length(const ntt_plan64 *plan, uint32_t *L);
+int ntt_poly_multiply64_batched(ntt_plan64 *plan, const uint64_t *a, const uint64_t *b, uint64_t *ab,
+                                size_t ab_stride, int batch);
+
 /* The two halves of ntt_crt_multiply as separate calls, for the prime-per-GPU sharding of the
  * reference's MPI driver (main-mpi.cc:657-660 gives each rank ceil(4/size) primes, :770 runs
  * process_mods_in_process on them, :772-796 gathers the residue polynomials and merges):

@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = (
     "poly_multiply", "ntt_ctx_create", "ntt_ctx_destroy", "ntt_ctx_set_stream", "ntt_ctx_stream",
     "ntt_ctx_synchronize", "ntt_plan_create", "ntt_plan_destroy", "ntt_plan_length",
     "ntt_poly_multiply_batched", "ntt_forward", "ntt_inverse", "ntt_crt_multiply", "ntt_crt_prime",
+    "ntt_plan64_create", "ntt_plan64_destroy", "ntt_plan64_length", "ntt_poly_multiply64_batched",
     "ntt_crt_residue_multiply", "ntt_crt_merge", "ntt_dist_plan_create", "ntt_dist_plan_destroy",
     "ntt_dist_colpass", "ntt_dist_local", "ntt_dist_local_length",
     "ntt_ctx_enable_kernel_timing", "ntt_ctx_kernel_time", "ntt_last_error", "ntt_read_case",
@@ -73,6 +74,10 @@ def _load():
     lib.ntt_inverse.argtypes = [vp, vp, i32]
     lib.ntt_crt_multiply.argtypes = [vp, vp, vp, vp, i32, u64]
     lib.ntt_crt_prime.argtypes = [i32, C.POINTER(u32)]
+    lib.ntt_plan64_create.argtypes = [vp, u64, i32, i32, C.POINTER(vp)]
+    lib.ntt_plan64_destroy.argtypes = [vp]
+    lib.ntt_plan64_length.argtypes = [vp, C.POINTER(u32)]
+    lib.ntt_poly_multiply64_batched.argtypes = [vp, vp, vp, vp, sz, i32]
     lib.ntt_crt_residue_multiply.argtypes = [vp, vp, vp, vp, i32, i32]
     lib.ntt_crt_merge.argtypes = [vp, vp, vp, vp, vp, vp, sz, u64]
     lib.ntt_dist_plan_create.argtypes = [vp, u32, i32, i32, i32, i32, C.POINTER(vp)]
@@ -140,6 +145,9 @@ class Context:
 
     def plan(self, p, n, batch=1, kind=MONTGOMERY):
         return Plan(self, p, n, batch, kind)
+
+    def plan64(self, p64, n, batch=1):
+        return Plan64(self, p64, n, batch)
 
     def crt_multiply(self, a, b, p64, out=None):
         """Large-modulus product (main-openmp.cc:693-711): a, b uint64 < p64; returns 2n-1 uint64."""
@@ -226,6 +234,42 @@ class Plan:
     def inverse(self, data, batch=1):
         _check(_lib.ntt_inverse(self._h, _ptr(data, np.uint32), batch))
         return data
+
+
+class Plan64:
+    """Products modulo one NTT-friendly prime below 2^62 with 64-bit lanes (``ntt_plan64``)."""
+
+    def __init__(self, ctx, p64, n, batch=1):
+        h = C.c_void_p()
+        _check(_lib.ntt_plan64_create(ctx._h, int(p64), int(n), int(batch), C.byref(h)))
+        self._h = h
+        self.ctx, self.p, self.n, self.batch = ctx, int(p64), int(n), int(batch)
+        L = C.c_uint32()
+        _check(_lib.ntt_plan64_length(h, C.byref(L)))
+        self.length = L.value
+
+    def close(self):
+        if self._h:
+            _lib.ntt_plan64_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def multiply(self, a, b, out=None, batch=None, out_stride=None):
+        """a, b: [batch, n] uint64 -> [batch, out_stride] uint64 holding 2n-1 coefficients per row."""
+        if batch is None:
+            batch = int(a.shape[0]) if getattr(a, "ndim", 1) == 2 or (hasattr(a, "dim") and a.dim() == 2) else 1
+        if out_stride is None:
+            out_stride = 2 * self.n - 1
+        if out is None:
+            out = np.zeros((batch, out_stride), dtype=np.uint64)
+        _check(_lib.ntt_poly_multiply64_batched(self._h, _ptr(a, np.uint64), _ptr(b, np.uint64),
+                                                _ptr(out, np.uint64), out_stride, batch))
+        return out
 
 
 class DistPlan:

@@ -1,0 +1,350 @@
+// direct64.cpp -- plans and launch sequence of the direct 64-bit path (kernels_u64.hip): polynomial
+// product modulo ONE NTT-friendly prime p64 < 2^62 with 64-bit Montgomery lanes.
+//
+// Reference counterpart: the single-modulus branch of main-openmp.cc:678-692 (toMontgomery,
+// NTT_iterative x2, pointwise ModMul, inverse, fromMontgomery) with `montgomery m(R = 2^60, p_)`
+// (:650-651), which the reference only takes for p_ < 2^50 and sends larger moduli through the
+// 4-prime CRT (:693-711, here ntt_crt_multiply).  This is the same branch with lanes wide enough
+// for the 51-bit modulus of the reference's fifth test case, so that case can be computed two ways.
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/ntt_amd.h"
+#include "engine.hpp"
+
+using namespace ntt;
+typedef unsigned __int128 u128;
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return ntt::fail(NTT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+struct ntt_plan64 {
+    ntt_ctx *ctx = nullptr;
+    uint64_t p = 0, g = 0;
+    int n = 0, logL = 0, batch = 0;
+    uint32_t L = 0;
+    ModParams64 mp{};
+    int nlevels = 0;
+    int level_log[8] = {0}, level_logM[8] = {0};
+    uint64_t *tw_fwd[8] = {nullptr}, *tw_inv[8] = {nullptr};
+    uint64_t *row_w = nullptr, *row_iw = nullptr;
+    Roots16x64 roots{}, iroots{};
+    uint64_t scale = 0;                     // L^-1 * R (cancels the pointwise R^-1), Montgomery form
+    DeviceBuffer work0, work1, stage_a, stage_b, stage_out;
+    std::vector<void *> owned;
+};
+
+namespace {
+
+uint64_t mulmod(uint64_t a, uint64_t b, uint64_t p) { return (uint64_t)((u128)a * b % p); }
+uint64_t powmod(uint64_t b, uint64_t e, uint64_t p)
+{
+    uint64_t r = 1 % p;
+    b %= p;
+    for (; e; e >>= 1, b = mulmod(b, b, p))
+        if (e & 1) r = mulmod(r, b, p);
+    return r;
+}
+// deterministic Miller-Rabin for 64-bit integers (the first twelve primes as bases)
+bool is_prime64(uint64_t n)
+{
+    if (n < 2) return false;
+    for (uint64_t q : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+        if (n % q == 0) return n == q;
+    }
+    uint64_t d = n - 1;
+    int s = 0;
+    while ((d & 1) == 0) { d >>= 1; ++s; }
+    for (uint64_t a : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+        uint64_t x = powmod(a, d, n);
+        if (x == 1 || x == n - 1) continue;
+        bool comp = true;
+        for (int i = 1; i < s && comp; ++i) {
+            x = mulmod(x, x, n);
+            if (x == n - 1) comp = false;
+        }
+        if (comp) return false;
+    }
+    return true;
+}
+uint64_t to_mont(uint64_t x, const ModParams64 &mp) { return (uint64_t)((((u128)x) << 64) % mp.p); }
+
+ModParams64 make_params(uint64_t p)
+{
+    ModParams64 m{};
+    m.p = p;
+    m.p2 = 2 * p;
+    uint64_t inv = 1;                                   // Newton: p^-1 mod 2^64
+    for (int i = 0; i < 6; ++i) inv *= 2 - p * inv;
+    m.nprime = 0 - inv;
+    m.r1 = (uint64_t)((((u128)1) << 64) % p);
+    m.r2 = mulmod(m.r1, m.r1, p);
+    return m;
+}
+
+// T[k][i] = c * w^(i*k) in Montgomery form, k < rows, i < cols
+std::vector<uint64_t> power_table(uint64_t w, uint32_t rows, uint32_t cols, uint64_t c, const ModParams64 &mp)
+{
+    std::vector<uint64_t> t((size_t)rows * cols);
+    uint64_t wk = 1;
+    for (uint32_t k = 0; k < rows; ++k) {
+        uint64_t cur = c;
+        for (uint32_t i = 0; i < cols; ++i) {
+            t[(size_t)k * cols + i] = to_mont(cur, mp);
+            cur = mulmod(cur, wk, mp.p);
+        }
+        wk = mulmod(wk, w, mp.p);
+    }
+    return t;
+}
+
+int upload(ntt_plan64 *pl, const std::vector<uint64_t> &h, uint64_t **dptr)
+{
+    void *d = nullptr;
+    HIP_TRY(hipMalloc(&d, h.size() * 8));
+    pl->owned.push_back(d);
+    HIP_TRY(hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    *dptr = static_cast<uint64_t *>(d);
+    return NTT_OK;
+}
+
+int build_tables(ntt_plan64 *pl)
+{
+    const ModParams64 &mp = pl->mp;
+    const uint64_t p = pl->p;
+    const uint32_t L = pl->L;
+    const uint64_t wL = powmod(pl->g, (p - 1) / L, p), iwL = powmod(wL, p - 2, p);
+    const uint64_t invL = powmod(L % p, p - 2, p);
+    const uint64_t scale = mulmod(invL, mp.r1, p);                  // L^-1 * R
+    pl->scale = to_mont(scale, mp);
+    const int rowlog = std::min(pl->logL, kRowLog);
+    const uint32_t len = 1u << rowlog;
+    // row tables: w_len^j, j < len/2
+    {
+        const uint64_t wr = powmod(wL, L / len, p), iwr = powmod(iwL, L / len, p);
+        std::vector<uint64_t> w(std::max<uint32_t>(len / 2, 1)), iw(std::max<uint32_t>(len / 2, 1));
+        uint64_t c = 1, ic = 1;
+        for (uint32_t j = 0; j < std::max<uint32_t>(len / 2, 1); ++j) {
+            w[j] = to_mont(c, mp);
+            iw[j] = to_mont(ic, mp);
+            c = mulmod(c, wr, p);
+            ic = mulmod(ic, iwr, p);
+        }
+        int rc = upload(pl, w, &pl->row_w);
+        if (rc) return rc;
+        if ((rc = upload(pl, iw, &pl->row_iw))) return rc;
+    }
+    if (pl->nlevels == 0) return NTT_OK;
+    const uint64_t w16 = powmod(wL, L / 16, p), iw16 = powmod(iwL, L / 16, p);
+    uint64_t c = 1, ic = 1;
+    for (int j = 0; j < 8; ++j) {
+        pl->roots.w[j] = to_mont(c, mp);
+        pl->iroots.w[j] = to_mont(ic, mp);
+        c = mulmod(c, w16, p);
+        ic = mulmod(ic, iw16, p);
+    }
+    for (int j = 0; j < pl->nlevels; ++j) {
+        const uint32_t M = 1u << pl->level_logM[j], N1 = 1u << pl->level_log[j], S = M / N1;
+        const uint64_t wM = powmod(wL, L / M, p), iwM = powmod(iwL, L / M, p);
+        const bool innermost = (j == pl->nlevels - 1);
+        int rc = upload(pl, power_table(wM, N1, S, 1, mp), &pl->tw_fwd[j]);
+        if (rc) return rc;
+        if ((rc = upload(pl, power_table(iwM, N1, S, innermost ? scale : 1, mp), &pl->tw_inv[j]))) return rc;
+    }
+    return NTT_OK;
+}
+
+Col64Args fill_col(ntt_plan64 *pl, int level, bool inverse, const uint64_t *in0, const uint64_t *in1, uint64_t *out0,
+                   uint64_t *out1, size_t in_stride, size_t out_stride, uint32_t in_len, uint32_t out_len, bool canon)
+{
+    Col64Args a{};
+    a.in[0] = in0; a.in[1] = in1;
+    a.out[0] = out0; a.out[1] = out1;
+    a.in_stride = in_stride; a.out_stride = out_stride;
+    a.in_len = in_len; a.out_len = out_len;
+    a.logM = pl->level_logM[level];
+    a.logS = pl->level_logM[level] - pl->level_log[level];
+    a.tw = inverse ? pl->tw_inv[level] : pl->tw_fwd[level];
+    a.use_scale0 = (inverse && level == pl->nlevels - 1) ? 1 : 0;
+    a.scale0 = pl->scale;
+    a.canon = canon ? 1 : 0;
+    a.roots = inverse ? pl->iroots : pl->roots;
+    return a;
+}
+
+// device pointers only; caller holds ctx->mu
+int multiply_device(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64_t *ab, size_t ab_stride, int batch)
+{
+    ntt_ctx *cx = pl->ctx;
+    const uint32_t n = (uint32_t)pl->n, L = pl->L, out_len = 2 * n - 1;
+    hipStream_t s = cx->stream;
+    cx->cur = s;
+    if (pl->nlevels == 0) {
+        Lds64Args r{};
+        r.a = a; r.b = b; r.out = ab;
+        r.in_stride = n; r.out_stride = ab_stride;
+        r.in_len = n; r.out_len = out_len;
+        r.blocks_per_row = 1; r.logLen = pl->logL;
+        r.w = pl->row_w; r.iw = pl->row_iw;
+        r.scale = pl->scale; r.use_scale = 1; r.canon = 1; r.mode = 0;
+        cx->begin(K_LDS64);
+        launch_lds64(r, pl->mp, (unsigned)batch, s);
+        cx->end();
+        HIP_TRY(hipGetLastError());
+        return NTT_OK;
+    }
+    int rc = pl->work0.ensure((size_t)pl->batch * L * 8);
+    if (!rc) rc = pl->work1.ensure((size_t)pl->batch * L * 8);
+    if (rc) return rc;
+    uint64_t *w0 = static_cast<uint64_t *>(pl->work0.ptr), *w1 = static_cast<uint64_t *>(pl->work1.ptr);
+    const int m = pl->nlevels;
+    // forward column levels, outermost first (operands a and b in one grid)
+    for (int j = 0; j < m; ++j) {
+        const Col64Args ca = j == 0 ? fill_col(pl, 0, false, a, b, w0, w1, n, L, n, L, false)
+                                    : fill_col(pl, j, false, w0, w1, w0, w1, L, L, L, L, false);
+        cx->begin(K_COL64);
+        launch_col64(pl->level_log[j], false, j == 0, ca, pl->mp, L >> pl->level_log[j], (unsigned)batch, 2, s);
+        cx->end();
+    }
+    // rows: forward a, forward b, pointwise, inverse
+    {
+        Lds64Args r{};
+        r.a = w0; r.b = w1; r.out = w0;
+        r.in_stride = L; r.out_stride = L;
+        r.in_len = L; r.out_len = L;
+        r.blocks_per_row = L >> kRowLog; r.logLen = kRowLog;
+        r.w = pl->row_w; r.iw = pl->row_iw;
+        r.use_scale = 0; r.canon = 0; r.mode = 0;
+        cx->begin(K_LDS64);
+        launch_lds64(r, pl->mp, (unsigned)batch * (L >> kRowLog), s);
+        cx->end();
+    }
+    // inverse column levels, innermost first; the outermost writes the caller's ab
+    for (int j = m - 1; j >= 0; --j) {
+        const Col64Args ca = j == 0 ? fill_col(pl, 0, true, w0, nullptr, ab, nullptr, L, ab_stride, L, out_len, true)
+                                    : fill_col(pl, j, true, w0, nullptr, w0, nullptr, L, L, L, L, false);
+        cx->begin(K_COL64);
+        launch_col64(pl->level_log[j], true, false, ca, pl->mp, L >> pl->level_log[j], (unsigned)batch, 1, s);
+        cx->end();
+    }
+    HIP_TRY(hipGetLastError());
+    return NTT_OK;
+}
+
+}  // namespace
+
+extern "C" int ntt_plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, ntt_plan64 **out)
+{
+    if (!ctx || !out) return fail(NTT_ERR_INVALID, "ntt_plan64_create: null argument");
+    if (n <= 0 || batch <= 0) return fail(NTT_ERR_INVALID, "ntt_plan64_create: n and batch must be positive");
+    if (n > (1 << 23)) return fail(NTT_ERR_UNSUPPORTED, "ntt_plan64_create: n above 2^23");
+    if (p64 < 3 || p64 >= (1ULL << 62) || !is_prime64(p64))
+        return fail(NTT_ERR_UNSUPPORTED, "ntt_plan64_create: p64 must be a prime below 2^62");
+    int lg = 1;
+    while ((1ull << lg) < 2ull * (uint64_t)n) ++lg;                // smallest power of two >= 2n, at least 2
+    if ((p64 - 1) % (1ull << lg) != 0)
+        return fail(NTT_ERR_UNSUPPORTED, "ntt_plan64_create: p64 - 1 is not divisible by the transform length");
+    if ((uint64_t)batch << lg > (1ull << 29))
+        return fail(NTT_ERR_UNSUPPORTED, "ntt_plan64_create: batch * L above 2^29 elements");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    auto *pl = new ntt_plan64();
+    pl->ctx = ctx;
+    pl->p = p64;
+    pl->n = n;
+    pl->batch = batch;
+    pl->logL = lg;
+    pl->L = 1u << lg;
+    pl->mp = make_params(p64);
+    // a quadratic non-residue g has g^((p-1)/L) of exact order L for every power of two L | p-1
+    // (the reference's primes all take g = 3, main-openmp.cc:635; so does 1337006139375617)
+    uint64_t g = 2;
+    while (powmod(g, (p64 - 1) / 2, p64) != p64 - 1) ++g;
+    pl->g = g;
+    if (lg > kRowLog) {
+        int rest = lg - kRowLog, m = 0, logM = lg;
+        while (rest > 0) {
+            const int l = std::min(rest, 4);
+            pl->level_log[m] = l;
+            pl->level_logM[m] = logM;
+            logM -= l;
+            rest -= l;
+            ++m;
+        }
+        pl->nlevels = m;
+    }
+    int rc = build_tables(pl);
+    if (rc) {
+        ntt_plan64_destroy(pl);
+        return rc;
+    }
+    *out = pl;
+    return NTT_OK;
+}
+
+extern "C" int ntt_plan64_destroy(ntt_plan64 *pl)
+{
+    if (!pl) return NTT_OK;
+    (void)hipSetDevice(pl->ctx->device);
+    (void)hipStreamSynchronize(pl->ctx->stream);
+    for (void *d : pl->owned) (void)hipFree(d);
+    pl->work0.release(); pl->work1.release();
+    pl->stage_a.release(); pl->stage_b.release(); pl->stage_out.release();
+    delete pl;
+    return NTT_OK;
+}
+
+extern "C" int ntt_plan64_length(const ntt_plan64 *pl, uint32_t *L)
+{
+    if (!pl || !L) return fail(NTT_ERR_INVALID, "ntt_plan64_length: null argument");
+    *L = pl->L;
+    return NTT_OK;
+}
+
+extern "C" int ntt_poly_multiply64_batched(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64_t *ab,
+                                           size_t ab_stride, int batch)
+{
+    if (!pl || !a || !b || !ab) return fail(NTT_ERR_INVALID, "ntt_poly_multiply64_batched: null argument");
+    if (batch <= 0 || batch > pl->batch)
+        return fail(NTT_ERR_INVALID, "ntt_poly_multiply64_batched: batch must be in 1..plan capacity");
+    const size_t n = (size_t)pl->n, out_len = 2 * n - 1;
+    if (ab_stride < out_len) return fail(NTT_ERR_INVALID, "ntt_poly_multiply64_batched: ab_stride < 2n-1");
+    ntt_ctx *cx = pl->ctx;
+    std::lock_guard<std::mutex> lk(cx->mu);
+    HIP_TRY(hipSetDevice(cx->device));
+    const bool dev_a = is_device_ptr(a), dev_b = is_device_ptr(b), dev_o = is_device_ptr(ab);
+    const uint64_t *da = a, *db = b;
+    uint64_t *dout = ab;
+    const size_t in_bytes = (size_t)batch * n * 8, out_elems = ((size_t)batch - 1) * ab_stride + out_len;
+    int rc;
+    if (!dev_a) {
+        if ((rc = pl->stage_a.ensure(in_bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(pl->stage_a.ptr, a, in_bytes, hipMemcpyHostToDevice, cx->stream));
+        da = static_cast<const uint64_t *>(pl->stage_a.ptr);
+    }
+    if (!dev_b) {
+        if ((rc = pl->stage_b.ensure(in_bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(pl->stage_b.ptr, b, in_bytes, hipMemcpyHostToDevice, cx->stream));
+        db = static_cast<const uint64_t *>(pl->stage_b.ptr);
+    }
+    if (!dev_o) {
+        if ((rc = pl->stage_out.ensure(out_elems * 8))) return rc;
+        dout = static_cast<uint64_t *>(pl->stage_out.ptr);
+        if (ab_stride != out_len)          // keep the caller's bytes between rows: entries >= 2n-1 are not ours
+            HIP_TRY(hipMemcpyAsync(dout, ab, out_elems * 8, hipMemcpyHostToDevice, cx->stream));
+    }
+    if ((rc = multiply_device(pl, da, db, dout, ab_stride, batch))) return rc;
+    if (!dev_o) {
+        HIP_TRY(hipMemcpyAsync(ab, dout, out_elems * 8, hipMemcpyDeviceToHost, cx->stream));
+        HIP_TRY(hipStreamSynchronize(cx->stream));
+    } else if (!dev_a || !dev_b) {
+        HIP_TRY(hipStreamSynchronize(cx->stream));
+    }
+    return NTT_OK;
+}

@@ -16,7 +16,8 @@
 namespace ntt {
 
 const char *const kKernelNames[K_COUNT] = {"col_fwd", "row_mul", "col_inv", "row_fwd", "row_inv",
-                                           "small", "permute", "crt_reduce", "crt_merge", "pipe"};
+                                           "small", "permute", "crt_reduce", "crt_merge", "pipe",
+                                           "col64", "lds64"};
 
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }

@@ -16,7 +16,7 @@ namespace ntt {
 
 enum KernelId {
     K_COL_FWD = 0, K_ROW_MUL, K_COL_INV, K_ROW_FWD, K_ROW_INV, K_SMALL, K_PERMUTE, K_CRT_REDUCE,
-    K_CRT_MERGE, K_PIPE, K_COUNT
+    K_CRT_MERGE, K_PIPE, K_COL64, K_LDS64, K_COUNT
 };
 extern const char *const kKernelNames[K_COUNT];
 

@@ -110,4 +110,39 @@ void launch_crt_reduce(const uint64_t *x, uint32_t *out, size_t n, const CrtPrim
 void launch_crt_merge(const uint32_t *const res[4], uint64_t *out, size_t n, const CrtConsts &cc,
                       hipStream_t s);
 
+// ---- direct 64-bit path (kernels_u64.hip): one NTT-friendly prime p < 2^62, Montgomery R = 2^64 ---------
+struct ModParams64 {
+    uint64_t p, p2, nprime;              // nprime = -p^-1 mod 2^64
+    uint64_t r1, r2;                     // 2^64 mod p, 2^128 mod p (host side: table construction)
+};
+struct Roots16x64 {
+    uint64_t w[8];                       // w_16^j (forward) or w_16^-j (inverse), Montgomery form
+};
+struct Col64Args {
+    const uint64_t *in[2];
+    uint64_t *out[2];
+    size_t in_stride, out_stride;
+    uint32_t in_len, out_len;
+    int logM, logS;
+    const uint64_t *tw;                  // [N1][S] 4-step twiddles, Montgomery form
+    uint64_t scale0;
+    int use_scale0;
+    int canon;
+    Roots16x64 roots;
+};
+struct Lds64Args {
+    const uint64_t *a, *b;
+    uint64_t *out;
+    size_t in_stride, out_stride;        // elements between batch rows
+    uint32_t in_len, out_len;            // valid elements per batch row
+    uint32_t blocks_per_row;
+    int logLen;                          // block length 2^logLen <= 4096
+    const uint64_t *w, *iw;              // w_len^j, w_len^-j, j < len/2, Montgomery form
+    uint64_t scale;
+    int use_scale, canon, mode;          // mode 0 multiply, 1 forward, 2 inverse
+};
+void launch_col64(int logN1, bool inverse, bool half_in, const Col64Args &a, const ModParams64 &mp,
+                  unsigned cols_per_row, unsigned batch, unsigned nops, hipStream_t s);
+void launch_lds64(const Lds64Args &a, const ModParams64 &mp, unsigned blocks, hipStream_t s);
+
 }  // namespace ntt

@@ -1,0 +1,243 @@
+// kernels_u64.hip -- direct path for ONE NTT-friendly prime p < 2^62: 64-bit Montgomery lanes, gfx950.
+//
+// The reference serves a modulus above 32 bits in two ways: the 4-prime CRT (main-openmp.cc:693-711,
+// here crt.cpp) and, for p_ < 2^50, the single-modulus branch main-openmp.cc:678-692 with 64-bit
+// lanes and `montgomery m(R = 2^60, p_)` (:650-651; its `power` limits it to 32-bit moduli in
+// practice).  These kernels are that single-modulus branch for any NTT-friendly prime below 2^62:
+// R = 2^64, one u64 per residue, lazy range [0, 2p).
+//
+//   REDC(T) for T = x * wR < 2^64 * p:  q = T_lo * (-p^-1) mod 2^64,  (T + q*p) / 2^64 in [0, 2p)
+//   = T_hi + mulhi(q, p) + (T_lo != 0)        (the low words cancel to exactly 0 or 2^64)
+//
+// Same decomposition as the 32-bit path: column levels of N1 <= 16 points in
+// registers with the 4-step twiddle from an HBM table, rows of 4096 points in a 32 KiB LDS tile.
+// The row transform is radix-2 in LDS: decimation in frequency forward (natural in, bit-reversed
+// out), decimation in time inverse (bit-reversed in, natural out), pointwise product in between --
+// no reordering pass.
+#include "kernels.hpp"
+
+namespace ntt {
+
+struct M64 {
+    static __device__ __forceinline__ uint64_t csub(uint64_t x, uint64_t m)
+    {
+        const uint64_t d = x - m;
+        return d < x ? d : x;               // x >= m  <=>  no wrap
+    }
+    // x * w for any u64 x, wR = w * 2^64 mod p (< p): result in [0, 2p)
+    static __device__ __forceinline__ uint64_t mulw(uint64_t x, uint64_t wR, const ModParams64 &m)
+    {
+        const uint64_t lo = x * wR, hi = __umul64hi(x, wR);
+        const uint64_t q = lo * m.nprime;
+        return hi + __umul64hi(q, m.p) + (lo != 0 ? 1u : 0u);
+    }
+    static __device__ __forceinline__ uint64_t add(uint64_t u, uint64_t v, const ModParams64 &m)
+    {
+        return csub(u + v, m.p2);
+    }
+    static __device__ __forceinline__ uint64_t sub(uint64_t u, uint64_t v, const ModParams64 &m)
+    {
+        return csub(u - v + m.p2, m.p2);
+    }
+    static __device__ __forceinline__ uint64_t sub_raw(uint64_t u, uint64_t v, const ModParams64 &m)
+    {
+        return u - v + m.p2;                // (0, 4p): valid mulw operand
+    }
+    static __device__ __forceinline__ uint64_t canon(uint64_t x, const ModParams64 &m) { return csub(x, m.p); }
+};
+
+__host__ __device__ constexpr int bitrev64_c(int x, int bits)
+{
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+// N-point transform in registers, N = 2^LOGN <= 16, natural in / natural out, values in [0, 2p).
+// roots.w[j] = w_16^j (forward or inverse table), so w_(2*half)^j = w[j * 8 / half].
+template <int LOGN, bool HALF>
+__device__ __forceinline__ void reg_ntt64(uint64_t (&x)[1 << LOGN], const Roots16x64 &roots, const ModParams64 &m)
+{
+    constexpr int N = 1 << LOGN;
+#pragma unroll
+    for (int s = 0; s < LOGN; ++s) {
+        const int half = N >> (s + 1);
+        const int step = 8 / half;
+#pragma unroll
+        for (int blk = 0; blk < N; blk += 2 * half) {
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                const uint64_t u = x[blk + j], v = x[blk + j + half];
+                if (HALF && s == 0) {
+                    x[blk + j + half] = j == 0 ? u : M64::mulw(u, roots.w[j * step], m);   // v == 0
+                } else {
+                    x[blk + j] = M64::add(u, v, m);
+                    x[blk + j + half] = j == 0 ? M64::sub(u, v, m) : M64::mulw(M64::sub_raw(u, v, m), roots.w[j * step], m);
+                }
+            }
+        }
+    }
+    uint64_t y[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[bitrev64_c(i, LOGN)] = x[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = y[i];
+}
+
+// ---- column pass ---------------------------------------------------------------------------------------
+// One thread per column of a block viewed as N1 x S (index maps as kernels_col.hip).
+template <int LOGN1, bool INVERSE, bool HALF>
+__global__ void __launch_bounds__(256) col64_kernel(const Col64Args a, const ModParams64 m)
+{
+    constexpr int N1 = 1 << LOGN1;
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t S = 1u << a.logS;
+    const uint32_t i2 = c & (S - 1);
+    const uint32_t base = ((c >> a.logS) << a.logM) + i2;
+    const int op = blockIdx.z;
+    const uint64_t *__restrict__ in = a.in[op] + (size_t)blockIdx.y * a.in_stride;
+    uint64_t *__restrict__ out = a.out[op] + (size_t)blockIdx.y * a.out_stride;
+    const uint64_t *__restrict__ tw = a.tw + i2;
+
+    uint64_t x[N1];
+#pragma unroll
+    for (int i1 = 0; i1 < N1; ++i1) {
+        if (HALF && i1 >= N1 / 2) {
+            x[i1] = 0;
+        } else {
+            const uint32_t idx = base + ((uint32_t)i1 << a.logS);
+            x[i1] = idx < a.in_len ? in[idx] : 0ull;
+        }
+    }
+    if constexpr (INVERSE) {
+        if (a.use_scale0) x[0] = M64::mulw(x[0], a.scale0, m);
+#pragma unroll
+        for (int k1 = 1; k1 < N1; ++k1) x[k1] = M64::mulw(x[k1], tw[(size_t)k1 << a.logS], m);
+    }
+    reg_ntt64<LOGN1, HALF>(x, a.roots, m);
+    if constexpr (!INVERSE) {
+#pragma unroll
+        for (int k1 = 1; k1 < N1; ++k1) x[k1] = M64::mulw(x[k1], tw[(size_t)k1 << a.logS], m);
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < N1; ++k1) {
+        const uint32_t idx = base + ((uint32_t)k1 << a.logS);
+        const uint64_t v = a.canon ? M64::canon(x[k1], m) : x[k1];
+        if (idx < a.out_len) out[idx] = v;
+    }
+}
+
+template <int LOGN1>
+static void launch_col64_t(bool inverse, bool half_in, const Col64Args &a, const ModParams64 &mp, dim3 grid, hipStream_t s)
+{
+    if (inverse) hipLaunchKernelGGL((col64_kernel<LOGN1, true, false>), grid, dim3(256), 0, s, a, mp);
+    else if (half_in) hipLaunchKernelGGL((col64_kernel<LOGN1, false, true>), grid, dim3(256), 0, s, a, mp);
+    else hipLaunchKernelGGL((col64_kernel<LOGN1, false, false>), grid, dim3(256), 0, s, a, mp);
+}
+
+void launch_col64(int logN1, bool inverse, bool half_in, const Col64Args &a, const ModParams64 &mp,
+                  unsigned cols_per_row, unsigned batch, unsigned nops, hipStream_t s)
+{
+    const dim3 grid(cols_per_row / 256, batch, nops);
+    switch (logN1) {
+    case 1: launch_col64_t<1>(inverse, half_in, a, mp, grid, s); break;
+    case 2: launch_col64_t<2>(inverse, half_in, a, mp, grid, s); break;
+    case 3: launch_col64_t<3>(inverse, half_in, a, mp, grid, s); break;
+    case 4: launch_col64_t<4>(inverse, half_in, a, mp, grid, s); break;
+    default: break;
+    }
+}
+
+// ---- LDS transform of one block of len = 2^logLen <= 4096 points ---------------------------------------
+// Forward: DIF, natural in -> bit-reversed out.  w[j] = w_len^j, j < len/2.
+__device__ __forceinline__ void lds_forward64(uint64_t *lds, int logLen, const uint64_t *__restrict__ w,
+                                              const ModParams64 &m)
+{
+    const uint32_t nb = 1u << (logLen - 1);             // butterflies per stage
+    for (int s = 0; s < logLen; ++s) {
+        const int lh = logLen - 1 - s;                  // log2(half)
+        for (uint32_t idx = threadIdx.x; idx < nb; idx += 256) {
+            const uint32_t j = idx & ((1u << lh) - 1);
+            const uint32_t i0 = ((idx >> lh) << (lh + 1)) + j, i1 = i0 + (1u << lh);
+            const uint64_t u = lds[i0], v = lds[i1];
+            lds[i0] = M64::add(u, v, m);
+            lds[i1] = M64::mulw(M64::sub_raw(u, v, m), w[j << s], m);
+        }
+        __syncthreads();
+    }
+}
+
+// Inverse: DIT, bit-reversed in -> natural out, unscaled.  iw[j] = w_len^-j.
+__device__ __forceinline__ void lds_inverse64(uint64_t *lds, int logLen, const uint64_t *__restrict__ iw,
+                                              const ModParams64 &m)
+{
+    const uint32_t nb = 1u << (logLen - 1);
+    for (int s = logLen - 1; s >= 0; --s) {
+        const int lh = logLen - 1 - s;
+        for (uint32_t idx = threadIdx.x; idx < nb; idx += 256) {
+            const uint32_t j = idx & ((1u << lh) - 1);
+            const uint32_t i0 = ((idx >> lh) << (lh + 1)) + j, i1 = i0 + (1u << lh);
+            const uint64_t u = lds[i0], v = M64::mulw(lds[i1], iw[j << s], m);
+            lds[i0] = M64::add(u, v, m);
+            lds[i1] = M64::sub(u, v, m);
+        }
+        __syncthreads();
+    }
+}
+
+// mode 0: multiply (forward a, forward b, pointwise, inverse); 1: forward only; 2: inverse only
+// (bit-reversed order on the spectrum side in every mode).  One workgroup per block of len points;
+// blocks_per_row blocks make one batch row (1 for the whole-transform case L <= 4096, L/4096 rows
+// otherwise).  `scale` (Montgomery form) multiplies the output when use_scale is set.
+__global__ void __launch_bounds__(256) lds64_kernel(const Lds64Args a, const ModParams64 m)
+{
+    __shared__ uint64_t lds[4096];
+    const uint32_t len = 1u << a.logLen;
+    const uint32_t blk = blockIdx.x % a.blocks_per_row, row = blockIdx.x / a.blocks_per_row;
+    const size_t off = (size_t)blk << a.logLen;
+    const uint64_t *__restrict__ pa = a.a + (size_t)row * a.in_stride + off;
+    uint64_t *__restrict__ po = a.out + (size_t)row * a.out_stride + off;
+    const uint32_t in_len = a.in_len, out_len = a.out_len;        // per row, relative to `off` = 0 when blocks_per_row == 1
+
+    for (uint32_t i = threadIdx.x; i < len; i += 256) lds[i] = (off + i) < in_len ? pa[i] : 0ull;
+    __syncthreads();
+    if (a.mode == 2) {
+        lds_inverse64(lds, a.logLen, a.iw, m);
+    } else {
+        lds_forward64(lds, a.logLen, a.w, m);
+        if (a.mode == 0) {
+            const uint64_t *__restrict__ pb = a.b + (size_t)row * a.in_stride + off;
+            uint64_t ra[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t i = threadIdx.x + 256u * k;
+                ra[k] = i < len ? lds[i] : 0ull;
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < len; i += 256) lds[i] = (off + i) < in_len ? pb[i] : 0ull;
+            __syncthreads();
+            lds_forward64(lds, a.logLen, a.w, m);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t i = threadIdx.x + 256u * k;
+                // REDC(a*b): a, b < 2p, a*b < 2^64 * p; the stray R^-1 is folded into the scale
+                if (i < len) lds[i] = M64::mulw(ra[k], lds[i], m);
+            }
+            __syncthreads();
+            lds_inverse64(lds, a.logLen, a.iw, m);
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < len; i += 256) {
+        uint64_t v = lds[i];
+        if (a.use_scale) v = M64::mulw(v, a.scale, m);
+        if (a.canon) v = M64::canon(v, m);
+        if ((off + i) < out_len) po[i] = v;
+    }
+}
+
+void launch_lds64(const Lds64Args &a, const ModParams64 &mp, unsigned blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(lds64_kernel, dim3(blocks), dim3(256), 0, s, a, mp);
+}
+
+}  // namespace ntt
