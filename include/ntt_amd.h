@@ -89,6 +89,19 @@ int ntt_plan_length(const ntt_plan *plan);
 int ntt_poly_multiply_batched(ntt_plan *plan, const uint32_t *a, const uint32_t *b, uint32_t *ab,
                               size_t ab_stride, int batch);
 
+/* Products whose operands live in HOST memory, streamed: a, b are [count][n] u32, ab is
+ * [count][ab_stride]; `count` is unbounded (slices of the plan's batch capacity travel host -> device
+ * -> multiply -> host on three streams, transfers of one slice overlapping the kernels of another).
+ * Pinned host memory (ntt_host_alloc) is read and written by DMA directly; pageable memory is staged
+ * through pinned bounce buffers.  Returns when ab is complete.  Entries >= 2n-1 of a row stay untouched.
+ * Same calling convention as the harness multiply body (host arrays in, host array out,
+ * main-montgomery.cc:297, :326-351) for any number of products; SURVEY 8f rank 2. */
+int ntt_poly_multiply_stream(ntt_plan *plan, const uint32_t *a, const uint32_t *b, uint32_t *ab,
+                             size_t ab_stride, size_t count);
+/* Page-locked host memory for the call above (hipHostMalloc / hipHostFree). */
+int ntt_host_alloc(size_t bytes, void **ptr);
+int ntt_host_free(void *ptr);
+
 /* Batched in-place transforms of length L = ntt_plan_length(plan): data is [batch][L] u32,
  * natural order in, natural order out, canonical residues, forward root g^((p-1)/L) with the
  * plan's generator g (g = 3 for the reference's primes), inverse scaled by L^-1.
@@ -180,6 +193,22 @@ int ntt_check_case(const char *dir, int id, const uint64_t *ab, int n);
 /* Replaces fWrite(int*ab,int n,int id): main-montgomery.cc:56-69.  Writes "<dir>/<id>.out",
  * one decimal per line. */
 int ntt_write_case(const char *dir, int id, const uint64_t *ab, int n);
+
+/* Packed binary cases: "<dir>/<id>.inb" / "<id>.outb" = 32-byte header
+ * {"NTTB", u32 version 1, u32 kind (1 inputs, 2 output), u32 width (4 | 8 bytes per coefficient),
+ * u64 n, u64 p} + little-endian coefficients (a then b, or ab).  Same content as the text files of
+ * fRead / fWrite (main-montgomery.cc:15-32, :56-69) without the decimal parsing; width 4 whenever
+ * p < 2^32, so a case loads straight into the arrays the multiply takes.
+ *   ntt_pack_case        text "<id>.in" (+ "<id>.out" when present) -> "<id>.inb" (+ "<id>.outb")
+ *   ntt_read_case_bin    a, b receive n coefficients of `width` bytes each (cap_bytes per array)
+ *   ntt_check_case_bin   compares ab (2n-1 coefficients of `width` bytes) with "<id>.outb", prints the
+ *                        reference's verdict line, returns NTT_OK / NTT_ERR_MISMATCH / NTT_ERR_IO
+ *   ntt_write_case_bin   writes "<id>.outb" */
+int ntt_pack_case(const char *dir, int id);
+int ntt_read_case_bin(const char *dir, int id, void *a, void *b, size_t cap_bytes, int *n, uint64_t *p,
+                      int *width);
+int ntt_check_case_bin(const char *dir, int id, const void *ab, int n, int width);
+int ntt_write_case_bin(const char *dir, int id, const void *ab, int n, uint64_t p, int width);
 
 #ifdef __cplusplus
 }

@@ -41,7 +41,8 @@ EXPORTED_SYMBOLS = (
     "ntt_crt_residue_multiply", "ntt_crt_merge", "ntt_dist_plan_create", "ntt_dist_plan_destroy",
     "ntt_dist_colpass", "ntt_dist_local", "ntt_dist_local_length",
     "ntt_ctx_enable_kernel_timing", "ntt_ctx_kernel_time", "ntt_last_error", "ntt_read_case",
-    "ntt_check_case", "ntt_write_case",
+    "ntt_check_case", "ntt_write_case", "ntt_poly_multiply_stream", "ntt_host_alloc", "ntt_host_free",
+    "ntt_pack_case", "ntt_read_case_bin", "ntt_check_case_bin", "ntt_write_case_bin",
 )
 
 
@@ -92,6 +93,13 @@ def _load():
     lib.ntt_read_case.argtypes = [C.c_char_p, i32, vp, vp, sz, C.POINTER(i32), C.POINTER(u64)]
     lib.ntt_check_case.argtypes = [C.c_char_p, i32, vp, i32]
     lib.ntt_write_case.argtypes = [C.c_char_p, i32, vp, i32]
+    lib.ntt_poly_multiply_stream.argtypes = [vp, vp, vp, vp, sz, sz]
+    lib.ntt_host_alloc.argtypes = [sz, C.POINTER(vp)]
+    lib.ntt_host_free.argtypes = [vp]
+    lib.ntt_pack_case.argtypes = [C.c_char_p, i32]
+    lib.ntt_read_case_bin.argtypes = [C.c_char_p, i32, vp, vp, sz, C.POINTER(i32), C.POINTER(u64), C.POINTER(i32)]
+    lib.ntt_check_case_bin.argtypes = [C.c_char_p, i32, vp, i32, i32]
+    lib.ntt_write_case_bin.argtypes = [C.c_char_p, i32, vp, i32, u64, i32]
     return lib
 
 
@@ -227,6 +235,18 @@ class Plan:
                                               _ptr(out, np.uint32), out_stride, batch))
         return out
 
+    def multiply_stream(self, a, b, out=None, out_stride=None):
+        """Host arrays a, b: [count, n] uint32, any count; slices stream through the GPU (pinned arrays
+        from ``host_array`` are DMA'd directly, pageable ones are staged).  Returns [count, out_stride]."""
+        count = int(a.shape[0])
+        if out_stride is None:
+            out_stride = 2 * self.n - 1
+        if out is None:
+            out = np.zeros((count, out_stride), dtype=np.uint32)
+        _check(_lib.ntt_poly_multiply_stream(self._h, _ptr(a, np.uint32), _ptr(b, np.uint32),
+                                             _ptr(out, np.uint32), out_stride, count))
+        return out
+
     def forward(self, data, batch=1):
         _check(_lib.ntt_forward(self._h, _ptr(data, np.uint32), batch))
         return data
@@ -302,6 +322,62 @@ class DistPlan:
         """S-point transform (natural order) of this rank's row, in place."""
         _check(_lib.ntt_dist_local(self._h, _ptr(row, np.uint32), 1 if inverse else 0))
         return row
+
+
+class _PinnedOwner:
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            _lib.ntt_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def host_array(shape, dtype=np.uint32):
+    """numpy array over page-locked host memory (``ntt_host_alloc``); freed with its last view."""
+    shape = tuple(int(x) for x in (shape if hasattr(shape, "__len__") else (shape,)))
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    _check(_lib.ntt_host_alloc(max(nbytes, 1), C.byref(p)))
+    owner = _PinnedOwner(p)
+    buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+    buf._owner = owner                     # the ctypes buffer (and every numpy view of it) keeps the memory alive
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
+def pack_case(directory, case_id):
+    _check(_lib.ntt_pack_case(str(directory).encode(), case_id))
+
+
+def read_case_bin(directory, case_id, cap=1 << 22):
+    """-> n, p, a, b with a, b uint32 (p < 2^32) or uint64 arrays, as stored."""
+    a = np.zeros(cap, dtype=np.uint64)
+    b = np.zeros(cap, dtype=np.uint64)
+    n, p, w = C.c_int(), C.c_uint64(), C.c_int()
+    _check(_lib.ntt_read_case_bin(str(directory).encode(), case_id, a.ctypes.data, b.ctypes.data, cap * 8,
+                                  C.byref(n), C.byref(p), C.byref(w)))
+    dt = np.uint32 if w.value == 4 else np.uint64
+    return n.value, p.value, a.view(dt)[:n.value].copy(), b.view(dt)[:n.value].copy()
+
+
+def check_case_bin(directory, case_id, ab):
+    ab = np.ascontiguousarray(ab)
+    assert ab.dtype in (np.uint32, np.uint64)
+    n = (ab.size + 1) // 2
+    rc = _lib.ntt_check_case_bin(str(directory).encode(), case_id, ab.ctypes.data, n, ab.dtype.itemsize)
+    if rc == ERR_MISMATCH:
+        return False
+    _check(rc)
+    return True
+
+
+def write_case_bin(directory, case_id, ab, p):
+    ab = np.ascontiguousarray(ab)
+    assert ab.dtype in (np.uint32, np.uint64)
+    n = (ab.size + 1) // 2
+    _check(_lib.ntt_write_case_bin(str(directory).encode(), case_id, ab.ctypes.data, n, int(p), ab.dtype.itemsize))
 
 
 def crt_prime(index):

@@ -352,7 +352,8 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
     const int m = pl->nlevels;
     ntt_ctx *cx = pl->ctx;
     const int nchunks = (batch + pl->chunk - 1) / pl->chunk;
-    const int lanes = std::min(std::min(pl->lanes, cx->nlanes), nchunks);
+    int lanes = std::min(std::min(pl->lanes, cx->nlanes), nchunks);
+    if (cx->lane_limit > 0) lanes = std::min(lanes, cx->lane_limit);
     if (lanes > 1) {                                      // fork: side lanes start after prior work
         (void)hipEventRecord(cx->fork_ev, cx->stream);
         for (int l = 1; l < lanes; ++l) (void)hipStreamWaitEvent(cx->lane[l], cx->fork_ev, 0);
@@ -593,6 +594,7 @@ int ntt_ctx_destroy(ntt_ctx *ctx)
     for (auto &kv : ctx->plan_cache) ntt_plan_destroy(kv.second);
     ctx->plan_cache.clear();
     ntt::crt_release(ctx);
+    ntt::stream_release(ctx);
     ctx->stage_a.release();
     ctx->stage_b.release();
     ctx->stage_out.release();

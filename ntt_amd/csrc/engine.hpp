@@ -37,6 +37,8 @@ struct CrtWorkspace {
     DeviceBuffer ra, rb, res, a64, b64, out64, merge_in;
 };
 void crt_release(ntt_ctx *ctx);
+struct StreamState;                       // stream.cpp: ring of device slots + copy streams
+void stream_release(ntt_ctx *ctx);
 const char *last_error_cstr();
 bool is_device_ptr(const void *p);
 
@@ -59,6 +61,7 @@ struct ntt_ctx {
     hipEvent_t lane_done[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr;
     hipStream_t cur = nullptr;                        // stream the next kernel goes to
+    int lane_limit = 0;                               // > 0: use at most this many lanes (stream.cpp)
     std::mutex mu;                                    // serialises calls on this handle
 
     // per-kernel timing (bench.py roofline block)
@@ -77,6 +80,7 @@ struct ntt_ctx {
     std::map<std::array<uint64_t, 3>, ntt_plan *> plan_cache;     // (p, n, kind): poly_multiply / CRT
     ntt::CrtWorkspace crt;
     ntt::DeviceBuffer stage_a, stage_b, stage_out;   // host-pointer staging
+    ntt::StreamState *stream_state = nullptr;        // ntt_poly_multiply_stream (stream.cpp)
 };
 
 struct ntt_plan {

@@ -99,6 +99,57 @@ def test_read_case_large_and_errors(nt, nttdata, tmp_path):
         nt.check_case(d, 9, np.zeros(3, dtype=np.uint64))
 
 
+def test_packed_case_roundtrip(nt, golden_dir, nttdata, tmp_path, capfd):
+    """Packed binary cases (ntt_pack_case / ntt_read_case_bin / ntt_check_case_bin / ntt_write_case_bin):
+    same content as the reference's text files, no decimal parsing."""
+    import struct
+    d = tmp_path
+    (d / "0.in").write_bytes(open(os.path.join(golden_dir, "nttdata_0.in"), "rb").read())
+    (d / "0.out").write_bytes(open(os.path.join(golden_dir, "nttdata_0.out"), "rb").read())
+    nt.pack_case(d, 0)
+    raw = (d / "0.inb").read_bytes()
+    assert raw[:4] == b"NTTB" and struct.unpack("<IIIQQ", raw[4:32]) == (1, 1, 4, 4, 7340033)
+    assert len(raw) == 32 + 2 * 4 * 4
+    n, p, a, b = nt.read_case_bin(d, 0)
+    assert (n, p) == (4, 7340033) and a.dtype == np.uint32
+    assert a.tolist() == [4, 1, 5, 2] and b.tolist() == [1, 5, 5, 4]
+    good = np.array([4, 21, 30, 48, 39, 30, 8], dtype=np.uint32)
+    assert nt.check_case_bin(d, 0, good) is True
+    assert "多项式乘法结果正确" in capfd.readouterr().out
+    bad = good.copy()
+    bad[6] ^= 1
+    assert nt.check_case_bin(d, 0, bad) is False
+    assert "多项式乘法结果错误" in capfd.readouterr().out
+    # a full-size case: packed files equal the golden arrays and are about half the size of the text
+    n1, p1, a1, b1, ab1 = nttdata[1]
+    with open(d / "1.in", "w") as f:
+        f.write(f"{n1} {p1}\n" + "".join(f"{v} " for v in a1) + "\n" + "".join(f"{v} " for v in b1))
+    with open(d / "1.out", "w") as f:
+        f.write("".join(f"{v} " for v in ab1))
+    nt.pack_case(d, 1)
+    n2, p2, a2, b2 = nt.read_case_bin(d, 1)
+    assert (n2, p2) == (n1, p1) and np.array_equal(a2, a1) and np.array_equal(b2, b1)
+    assert nt.check_case_bin(d, 1, ab1.astype(np.uint32)) is True
+    assert os.path.getsize(d / "1.inb") == 32 + 8 * n1 < os.path.getsize(d / "1.in") * 0.6
+    # 64-bit coefficients when p needs them; inputs without an expected output pack too
+    with open(d / "4.in", "w") as f:
+        f.write("2 1337006139375617\n1337006139375616 5 \n7 1337006139375000 ")
+    nt.pack_case(d, 4)
+    assert not (d / "4.outb").exists()
+    n4, p4, a4, b4 = nt.read_case_bin(d, 4)
+    assert p4 == 1337006139375617 and a4.dtype == np.uint64 and a4.tolist() == [1337006139375616, 5]
+    out = np.array([1, 2, 1337006139375616], dtype=np.uint64)
+    nt.write_case_bin(d, 4, out, p4)
+    assert nt.check_case_bin(d, 4, out) is True
+    with pytest.raises(nt.NttError):
+        nt.check_case_bin(d, 4, out.astype(np.uint32))           # width differs from the file
+    with pytest.raises(nt.NttError):
+        nt.read_case_bin(d, 9)
+    (d / "7.inb").write_bytes(b"NTTX" + raw[4:])
+    with pytest.raises(nt.NttError):
+        nt.read_case_bin(d, 7)
+
+
 def test_no_cpu_fallback(nt):
     import torch
     if torch.cuda.is_available():

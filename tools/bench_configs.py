@@ -56,6 +56,29 @@ def main():
                       "batch": B, "poly_mults_per_s": B / dt, "GBps_over_pcie": B * (16 * n - 4) / dt / 1e9}), flush=True)
     plan.close()
 
+    # ---- the same with the streaming entry point: slices of 64 products in a three-slot ring, copies and
+    # kernels on separate streams; pageable arrays are staged through pinned bounce buffers, pinned
+    # arrays (ntt_host_alloc) are read and written by DMA directly
+    B = 1024
+    plan = ctx.plan(p, n, 64, ntt_amd.MONTGOMERY)
+    pa, pb = ntt_amd.host_array((B, n)), ntt_amd.host_array((B, n))
+    pab = ntt_amd.host_array((B, 2 * n - 1))
+    pa[:] = (orc.splitmix64_np(1, B * n) % np.uint64(p)).astype(np.uint32).reshape(B, n)
+    pb[:] = (orc.splitmix64_np(2, B * n) % np.uint64(p)).astype(np.uint32).reshape(B, n)
+    qa, qb = np.array(pa), np.array(pb)                      # pageable copies
+    qab = np.zeros((B, 2 * n - 1), dtype=np.uint32)
+    for name, (xa_, xb_, xo_) in (("pinned", (pa, pb, pab)), ("pageable", (qa, qb, qab))):
+        plan.multiply_stream(xa_[:128], xb_[:128], out=xo_[:128])
+        t0 = time.perf_counter()
+        plan.multiply_stream(xa_, xb_, out=xo_)
+        dt = time.perf_counter() - t0
+        print(json.dumps({"config": "1 streamed from %s HOST arrays (ntt_poly_multiply_stream, 1024 products)" % name,
+                          "poly_mults_per_s": B / dt, "GBps_each_way_over_pcie": B * (8 * n) / dt / 1e9}), flush=True)
+    assert np.array_equal(pab, qab)
+    assert np.array_equal(hab[:4], pab[:4])
+    plan.close()
+    del pa, pb, pab, qa, qb, qab
+
     # ---- config 3 ------------------------------------------------------------------------------
     n, p64 = 131072, 1337006139375617
     a = orc.splitmix64_np(0x20250711, n) % np.uint64(p64)
@@ -79,6 +102,32 @@ def main():
                       "ms_per_product": dt * 1e3, "products_per_s": 1 / dt,
                       "cpu_oracle_ms_per_product": cpu_s * 1e3,
                       "reference_published_ms": 90.7393}), flush=True)
+
+    # ---- config 3 through the direct 64-bit path (one 64-bit transform per operand instead of four primes)
+    plan64 = ctx.plan64(p64, n, batch=64)
+    plan64.multiply(da, db, out=dab, batch=1)
+    sync()
+    assert np.array_equal(dab.cpu().numpy().view(np.uint64), want)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        plan64.multiply(da, db, out=dab, batch=1)
+    sync()
+    dt1 = (time.perf_counter() - t0) / reps
+    B64 = 64
+    xa = torch.from_numpy((orc.splitmix64_np(5, B64 * n) % np.uint64(p64)).view(np.int64).reshape(B64, n)).cuda()
+    xb = torch.from_numpy((orc.splitmix64_np(6, B64 * n) % np.uint64(p64)).view(np.int64).reshape(B64, n)).cuda()
+    xo = torch.zeros((B64, 2 * n), dtype=torch.int64, device="cuda")
+    plan64.multiply(xa, xb, out=xo, batch=B64, out_stride=2 * n)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        plan64.multiply(xa, xb, out=xo, batch=B64, out_stride=2 * n)
+    sync()
+    dtb = (time.perf_counter() - t0) / 10 / B64
+    print(json.dumps({"config": "3 via the direct 64-bit path (ntt_plan64), n=2^17, p=1337006139375617, device-resident",
+                      "ms_per_product_single": dt1 * 1e3, "ms_per_product_batch64": dtb * 1e3,
+                      "products_per_s_batch64": 1 / dtb}), flush=True)
+    plan64.close()
 
     # ---- config 4 ------------------------------------------------------------------------------
     n, limbs, per = 65536, 32, 256
