@@ -9,6 +9,9 @@
 // instead of producing a spurious verdict, and the exit status is non-zero on any mismatch.
 //
 //   ntt_cli [--data DIR] [--out DIR] [--begin N] [--end N] [--epochs N] [--barrett]
+//           [--pack]      convert "<id>.in" / "<id>.out" to the packed "<id>.inb" / "<id>.outb" and exit
+//           [--bin]       read, check and write the packed files instead of the text ones
+//           [--direct64]  moduli above 2^31: one 64-bit transform (ntt_plan64) instead of the 4-prime CRT
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -24,6 +27,7 @@ int main(int argc, char **argv)
 {
     std::string data = "./nttdata", out = "./files";
     int begin = 0, end = 4, epochs = 50, kind = NTT_MODMUL_MONTGOMERY;
+    bool pack = false, bin = false, direct64 = false;
     for (int i = 1; i < argc; ++i) {
         auto need = [&](const char *flag) -> const char * {
             if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", flag); std::exit(2); }
@@ -35,9 +39,22 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--end")) end = std::atoi(need("--end"));
         else if (!std::strcmp(argv[i], "--epochs")) epochs = std::atoi(need("--epochs"));
         else if (!std::strcmp(argv[i], "--barrett")) kind = NTT_MODMUL_BARRETT;
+        else if (!std::strcmp(argv[i], "--pack")) pack = true;
+        else if (!std::strcmp(argv[i], "--bin")) bin = true;
+        else if (!std::strcmp(argv[i], "--direct64")) direct64 = true;
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
     if (epochs < 1) epochs = 1;
+    if (pack) {                                          // host-only: no GPU needed
+        int failed = 0;
+        for (int id = begin; id <= end; ++id) {
+            if (ntt_pack_case(data.c_str(), id) != NTT_OK) {
+                std::fprintf(stderr, "case %d not packed: %s\n", id, ntt_last_error());
+                ++failed;
+            }
+        }
+        return failed ? 1 : 0;
+    }
     ntt_ctx *ctx = nullptr;
     int dev = 0;
     if (ntt_ctx_create(&dev, 1, &ctx) != NTT_OK) {
@@ -50,7 +67,17 @@ int main(int argc, char **argv)
     for (int id = begin; id <= end; ++id) {
         int n = 0;
         uint64_t p = 0;
-        int rc = ntt_read_case(data.c_str(), id, a.data(), b.data(), cap, &n, &p);
+        int rc, width = 8;
+        if (bin) {
+            rc = ntt_read_case_bin(data.c_str(), id, a.data(), b.data(), cap * 8, &n, &p, &width);
+            if (rc == NTT_OK && width == 4) {            // widen in place, back to front
+                const uint32_t *a4 = reinterpret_cast<const uint32_t *>(a.data());
+                const uint32_t *b4 = reinterpret_cast<const uint32_t *>(b.data());
+                for (int i = n - 1; i >= 0; --i) { a[i] = a4[i]; b[i] = b4[i]; }
+            }
+        } else {
+            rc = ntt_read_case(data.c_str(), id, a.data(), b.data(), cap, &n, &p);
+        }
         if (rc != NTT_OK) {
             std::fprintf(stderr, "case %d skipped: %s\n", id, ntt_last_error());
             continue;
@@ -84,6 +111,21 @@ int main(int argc, char **argv)
             (void)hipFree(da); (void)hipFree(db); (void)hipFree(dab);
             ntt_plan_destroy(plan);
             for (size_t i = 0; i < ab32.size(); ++i) ab[i] = ab32[i];
+        } else if (direct64) {
+            ntt_plan64 *plan = nullptr;
+            if (ntt_plan64_create(ctx, p, n, 1, &plan) != NTT_OK) {
+                std::fprintf(stderr, "case %d: %s\n", id, ntt_last_error());
+                ++bad;
+                continue;
+            }
+            for (int e = 0; e < epochs + 1; ++e) {
+                auto t0 = std::chrono::high_resolution_clock::now();
+                rc = ntt_poly_multiply64_batched(plan, a.data(), b.data(), ab.data(), ab.size(), 1);
+                auto t1 = std::chrono::high_resolution_clock::now();
+                if (rc != NTT_OK) break;
+                if (e > 0) total_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+            }
+            ntt_plan64_destroy(plan);
         } else {
             for (int e = 0; e < epochs + 1; ++e) {
                 auto t0 = std::chrono::high_resolution_clock::now();
@@ -98,12 +140,18 @@ int main(int argc, char **argv)
             ++bad;
             continue;
         }
-        rc = ntt_check_case(data.c_str(), id, ab.data(), n);
+        std::vector<uint32_t> ab4;
+        if (bin && width == 4) {
+            ab4.resize(ab.size());
+            for (size_t i = 0; i < ab.size(); ++i) ab4[i] = (uint32_t)ab[i];
+        }
+        const void *abw = (bin && width == 4) ? (const void *)ab4.data() : (const void *)ab.data();
+        rc = bin ? ntt_check_case_bin(data.c_str(), id, abw, n, width) : ntt_check_case(data.c_str(), id, ab.data(), n);
         if (rc == NTT_ERR_MISMATCH) ++bad;
         else if (rc != NTT_OK) std::fprintf(stderr, "case %d not checked: %s\n", id, ntt_last_error());
         std::printf("average latency for n = %d p = %llu : %g (us) \n", n, (unsigned long long)p,
                     total_ms / epochs);
-        if (ntt_write_case(out.c_str(), id, ab.data(), n) != NTT_OK)
+        if ((bin ? ntt_write_case_bin(out.c_str(), id, abw, n, p, width) : ntt_write_case(out.c_str(), id, ab.data(), n)) != NTT_OK)
             std::fprintf(stderr, "case %d not written: %s\n", id, ntt_last_error());
     }
     ntt_ctx_destroy(ctx);

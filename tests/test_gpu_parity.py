@@ -556,6 +556,18 @@ def test_cli_harness_loop(nt, nttdata, tmp_path):
         got = np.loadtxt(out / "1.out", dtype=np.uint64)   # fWrite format: one value per line
         assert np.array_equal(got.astype(np.uint32), ab)
         assert np.array_equal(np.loadtxt(out / "4.out", dtype=np.uint64), ab4)
+    # packed cases: --pack converts the text files, --bin runs the same loop on them; --direct64 sends the
+    # 51-bit case through one 64-bit transform instead of the 4-prime CRT
+    r = subprocess.run([exe, "--data", str(data), "--pack", "--begin", "0", "--end", "4"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 1 and "case 2 not packed" in r.stderr      # 2.in is missing, the others convert
+    assert (data / "1.inb").exists() and (data / "4.outb").exists()
+    r = subprocess.run([exe, "--data", str(data), "--out", str(out), "--begin", "0", "--end", "4", "--epochs", "2",
+                        "--bin", "--direct64"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("多项式乘法结果正确") == 4 and "多项式乘法结果错误" not in r.stdout
+    assert nt.check_case_bin(out, 4, ab4) is True                     # the written packed result
+    assert nt.check_case_bin(out, 3, nttdata[3][4].astype(np.uint32)) is True
     # a wrong expected file must flip the verdict and the exit status
     with open(data / "0.out", "w") as f:
         f.write("4 21 30 48 39 30 9 ")
