@@ -89,6 +89,18 @@ int ntt_plan_length(const ntt_plan *plan);
 int ntt_poly_multiply_batched(ntt_plan *plan, const uint32_t *a, const uint32_t *b, uint32_t *ab,
                               size_t ab_stride, int batch);
 
+/* Negacyclic products: c = a * b mod (x^n + 1, p), n a power of two with
+ * 2n | p - 1: a, b are [batch][n] u32, c is [batch][n] canonical residues with row stride c_stride
+ * (>= n).  One transform of length n per operand (no zero padding); the twist by psi^i
+ * (psi = g^((p-1)/2n)) is fused into the first forward pass and psi^-i into the last inverse pass.
+ * The reference has no negacyclic routine: it is the ring FHE-style RNS workloads (BASELINE.json
+ * configs[3]'s namesake) multiply in, built from the same NTT_iterative replacement
+ * (main-montgomery.cc:255-295); its definition here is c[i] = ab[i] - ab[i+n] of the linear product.
+ * ntt_forward / ntt_inverse on such a plan are the plain cyclic transforms of length n. */
+int ntt_negacyclic_plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind, ntt_plan **out);
+int ntt_negacyclic_multiply_batched(ntt_plan *plan, const uint32_t *a, const uint32_t *b, uint32_t *c,
+                                    size_t c_stride, int batch);
+
 /* Products whose operands live in HOST memory, streamed: a, b are [count][n] u32, ab is
  * [count][ab_stride]; `count` is unbounded (slices of the plan's batch capacity travel host -> device
  * -> multiply -> host on three streams, transfers of one slice overlapping the kernels of another).

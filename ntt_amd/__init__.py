@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = (
     "poly_multiply", "ntt_ctx_create", "ntt_ctx_destroy", "ntt_ctx_set_stream", "ntt_ctx_stream",
     "ntt_ctx_synchronize", "ntt_plan_create", "ntt_plan_destroy", "ntt_plan_length",
     "ntt_poly_multiply_batched", "ntt_forward", "ntt_inverse", "ntt_crt_multiply", "ntt_crt_prime",
+    "ntt_negacyclic_plan_create", "ntt_negacyclic_multiply_batched",
     "ntt_plan64_create", "ntt_plan64_destroy", "ntt_plan64_length", "ntt_poly_multiply64_batched",
     "ntt_crt_residue_multiply", "ntt_crt_merge", "ntt_dist_plan_create", "ntt_dist_plan_destroy",
     "ntt_dist_colpass", "ntt_dist_local", "ntt_dist_local_length",
@@ -75,6 +76,8 @@ def _load():
     lib.ntt_inverse.argtypes = [vp, vp, i32]
     lib.ntt_crt_multiply.argtypes = [vp, vp, vp, vp, i32, u64]
     lib.ntt_crt_prime.argtypes = [i32, C.POINTER(u32)]
+    lib.ntt_negacyclic_plan_create.argtypes = [vp, u32, i32, i32, i32, C.POINTER(vp)]
+    lib.ntt_negacyclic_multiply_batched.argtypes = [vp, vp, vp, vp, sz, i32]
     lib.ntt_plan64_create.argtypes = [vp, u64, i32, i32, C.POINTER(vp)]
     lib.ntt_plan64_destroy.argtypes = [vp]
     lib.ntt_plan64_length.argtypes = [vp, C.POINTER(u32)]
@@ -153,6 +156,9 @@ class Context:
 
     def plan(self, p, n, batch=1, kind=MONTGOMERY):
         return Plan(self, p, n, batch, kind)
+
+    def negacyclic_plan(self, p, n, batch=1, kind=MONTGOMERY):
+        return NegacyclicPlan(self, p, n, batch, kind)
 
     def plan64(self, p64, n, batch=1):
         return Plan64(self, p64, n, batch)
@@ -254,6 +260,29 @@ class Plan:
     def inverse(self, data, batch=1):
         _check(_lib.ntt_inverse(self._h, _ptr(data, np.uint32), batch))
         return data
+
+
+class NegacyclicPlan(Plan):
+    """Products modulo (x^n + 1, p): ``ntt_negacyclic_plan_create`` / ``ntt_negacyclic_multiply_batched``."""
+
+    def __init__(self, ctx, p, n, batch=1, kind=MONTGOMERY):
+        h = C.c_void_p()
+        _check(_lib.ntt_negacyclic_plan_create(ctx._h, int(p), int(n), int(batch), int(kind), C.byref(h)))
+        self._h = h
+        self.ctx, self.p, self.n, self.batch, self.kind = ctx, int(p), int(n), int(batch), kind
+        self.length = _lib.ntt_plan_length(h)
+
+    def multiply(self, a, b, out=None, batch=None, out_stride=None):
+        """a, b: [batch, n] uint32 -> [batch, out_stride] uint32 holding the n coefficients of a*b mod x^n+1."""
+        if batch is None:
+            batch = int(a.shape[0]) if getattr(a, "ndim", 1) == 2 or (hasattr(a, "dim") and a.dim() == 2) else 1
+        if out_stride is None:
+            out_stride = self.n
+        if out is None:
+            out = np.zeros((batch, out_stride), dtype=np.uint32)
+        _check(_lib.ntt_negacyclic_multiply_batched(self._h, _ptr(a, np.uint32), _ptr(b, np.uint32),
+                                                    _ptr(out, np.uint32), out_stride, batch))
+        return out
 
 
 class Plan64:

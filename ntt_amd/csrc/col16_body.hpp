@@ -43,6 +43,9 @@ __device__ __forceinline__ void col16_body(const ColArgs<MM> &a, const ModParams
         } else {
             const uint32_t row = (uint32_t)(R * j + r);                // wave-uniform
             uint32_t v = buf_load(rin, voff + (row << rowsh), 0);
+            if (!INVERSE && a.twist)                                   // negacyclic: x[i] * psi^i (uniform)
+                v = O::mul_tw(v, buf_load_tw<tw_t>(make_buf(a.twist, (uint32_t)sizeof(tw_t) << a.logM),
+                                                   base * (uint32_t)sizeof(tw_t), row << twsh), m);
             if constexpr (INVERSE) {
                 // inputs may be loose: every row is multiplied, except row 0 of an outer level
                 if (row == 0) v = a.use_scale0 ? O::mul_tw(v, a.scale0, m) : O::tighten(v, m);
@@ -85,8 +88,12 @@ __device__ __forceinline__ void col16_body(const ColArgs<MM> &a, const ModParams
                 if constexpr (!INVERSE) {
                     v = row != 0 ? O::mul_tw(v, buf_load_tw<tw_t>(rtw, twoff, row << twsh), m) : O::tighten(v, m);
                     if constexpr (CANON) v = O::canon(v, m);
-                } else {
-                    if constexpr (CANON) v = O::canon(O::tighten(v, m), m);
+                } else if constexpr (CANON) {
+                    if (a.twist)                                       // negacyclic: result * psi^-i (uniform)
+                        v = O::canon(O::mul_tw(v, buf_load_tw<tw_t>(make_buf(a.twist, (uint32_t)sizeof(tw_t) << a.logM),
+                                                                    base * (uint32_t)sizeof(tw_t), row << twsh), m), m);
+                    else
+                        v = O::canon(O::tighten(v, m), m);
                 }
                 buf_store(v, rout, voff + (row << rowsh), 0);
             }

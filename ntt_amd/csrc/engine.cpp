@@ -130,6 +130,19 @@ static int build_tables(ntt_plan *pl)
     pl->scale_mul = bytes_of_tw<MM>(scale_mul, mp);
     pl->scale_plain = bytes_of_tw<MM>(invL, mp);
 
+    if (pl->negacyclic) {
+        // psi = g^((p-1)/2L), psi^2 = wL: a * psi^i, cyclic transform of length L = n, result * psi^-i
+        const uint32_t psi = h_powmod(pl->g, (p - 1) / (2 * L), p), ipsi = h_powmod(psi, p - 2, p);
+        int rc = upload_table<MM>(pl, power_table<MM>(psi, 2, L, 1, mp), &pl->twist_fwd);      // row 1 = psi^i
+        if (rc) return rc;
+        pl->twist_fwd = static_cast<typename MM::tw_t *>(pl->twist_fwd) + L;
+        rc = upload_table<MM>(pl, power_table<MM>(ipsi, 2, L, 1, mp), &pl->twist_inv);
+        if (rc) return rc;
+        pl->twist_inv = static_cast<typename MM::tw_t *>(pl->twist_inv) + L;
+        rc = upload_table<MM>(pl, power_table<MM>(ipsi, 2, L, scale_mul, mp), &pl->small_itwist);
+        if (rc) return rc;
+        pl->small_itwist = static_cast<typename MM::tw_t *>(pl->small_itwist) + L;
+    }
     if (pl->logL <= kRowLog) {
         std::vector<typename MM::tw_t> w(std::max<uint32_t>(L / 2, 1)), iw(std::max<uint32_t>(L / 2, 1));
         uint32_t c = 1, ic = 1;
@@ -210,9 +223,10 @@ template <class MM>
 static ColArgs<MM> fill_col(ntt_plan *pl, int level, bool inverse, const uint32_t *in0, const uint32_t *in1,
                             uint32_t *out0, uint32_t *out1, size_t in_stride, size_t out_stride,
                             uint32_t in_len, uint32_t out_len, const void *tw, bool use_scale0,
-                            const std::vector<unsigned char> &scale0, bool canon)
+                            const std::vector<unsigned char> &scale0, bool canon, const void *twist = nullptr)
 {
     ColArgs<MM> a{};
+    a.twist = static_cast<const typename MM::tw_t *>(twist);
     a.in[0] = in0; a.in[1] = in1;
     a.out[0] = out0; a.out[1] = out1;
     a.in_stride = in_stride; a.out_stride = out_stride;
@@ -236,10 +250,10 @@ static void col_pass(ntt_plan *pl, int level, bool inverse, bool half_in, const 
                      const uint32_t *in1, uint32_t *out0, uint32_t *out1, size_t in_stride,
                      size_t out_stride, uint32_t in_len, uint32_t out_len, const void *tw,
                      bool use_scale0, const std::vector<unsigned char> &scale0, bool canon,
-                     unsigned batch, unsigned nops)
+                     unsigned batch, unsigned nops, const void *twist = nullptr)
 {
     ColArgs<MM> a = fill_col<MM>(pl, level, inverse, in0, in1, out0, out1, in_stride, out_stride, in_len,
-                                 out_len, tw, use_scale0, scale0, canon);
+                                 out_len, tw, use_scale0, scale0, canon, twist);
     ntt_ctx *cx = pl->ctx;
     const bool col16 = (inverse ? pl->col16_inv : pl->col16_fwd) && pl->level_log[level] >= 5;
     cx->begin(inverse ? K_COL_INV : K_COL_FWD);
@@ -331,6 +345,10 @@ static void small_pass(ntt_plan *pl, int mode, const uint32_t *a0, const uint32_
     a.iw = static_cast<const typename MM::tw_t *>(pl->small_iw);
     std::memcpy(&a.scale, (mode == 0 ? pl->scale_mul : pl->scale_plain).data(), sizeof(a.scale));
     a.mode = mode;
+    if (mode == 0 && pl->negacyclic) {
+        a.twist = static_cast<const typename MM::tw_t *>(pl->twist_fwd);
+        a.itwist = static_cast<const typename MM::tw_t *>(pl->small_itwist);
+    }
     ntt_ctx *cx = pl->ctx;
     cx->begin(K_SMALL);
     launch_small(pl->kind, pl->lazy, &a, pl->mp, batch, cx->cur);
@@ -342,13 +360,15 @@ template <class MM>
 static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
                            size_t ab_stride, int batch)
 {
-    const uint32_t n = (uint32_t)pl->n, L = pl->L, out_len = 2 * n - 1;
+    // negacyclic plans: L = n, no zero padding, n outputs, operands and result twisted by psi^(+-i)
+    const bool neg = pl->negacyclic;
+    const uint32_t n = (uint32_t)pl->n, L = pl->L, out_len = neg ? n : 2 * n - 1;
     pl->ctx->cur = pl->ctx->stream;
     if (pl->logL <= kRowLog) {
         small_pass<MM>(pl, 0, a, b, ab, n, ab_stride, n, out_len, (unsigned)batch);
         return NTT_OK;
     }
-    if (pl->pipe) return multiply_pipelined<MM>(pl, a, b, ab, ab_stride, batch);
+    if (pl->pipe && !neg) return multiply_pipelined<MM>(pl, a, b, ab, ab_stride, batch);
     const int m = pl->nlevels;
     ntt_ctx *cx = pl->ctx;
     const int nchunks = (batch + pl->chunk - 1) / pl->chunk;
@@ -368,7 +388,8 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
         const uint32_t *ca = a + (size_t)c0 * n, *cbp = b + (size_t)c0 * n;
         // forward column levels (both operands per launch); level 0 reads the caller's arrays with
         // implicit zero padding (n <= L/2: the upper half of every column is zero)
-        col_pass<MM>(pl, 0, false, true, ca, cbp, w0, w1, n, L, n, L, pl->tw_fwd[0], false, {}, false, cb, 2);
+        col_pass<MM>(pl, 0, false, !neg, ca, cbp, w0, w1, n, L, n, L, pl->tw_fwd[0], false, {}, false, cb, 2,
+                     neg ? pl->twist_fwd : nullptr);
         for (int j = 1; j < m; ++j)
             col_pass<MM>(pl, j, false, false, w0, w1, w0, w1, L, L, L, L, pl->tw_fwd[j], false, {}, false, cb, 2);
         // rows: forward a, forward b, pointwise, inverse
@@ -378,7 +399,7 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
             col_pass<MM>(pl, j, true, false, w0, nullptr, w0, nullptr, L, L, L, L, pl->tw_inv[j],
                          j == m - 1, pl->scale_mul, false, cb, 1);
         col_pass<MM>(pl, 0, true, false, w0, nullptr, ab + (size_t)c0 * ab_stride, nullptr, L, ab_stride,
-                     L, out_len, pl->tw_inv[0], m == 1, pl->scale_mul, true, cb, 1);
+                     L, out_len, pl->tw_inv[0], m == 1, pl->scale_mul, true, cb, 1, neg ? pl->twist_inv : nullptr);
     }
     cx->cur = cx->stream;
     if (lanes > 1) {                                      // join
@@ -610,7 +631,20 @@ int ntt_ctx_destroy(ntt_ctx *ctx)
     return NTT_OK;
 }
 
+static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind, bool negacyclic, ntt_plan **out_plan);
+
 int ntt_plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind, ntt_plan **out_plan)
+{
+    return plan_create(ctx, p, n, batch, modmul_kind, false, out_plan);
+}
+
+int ntt_negacyclic_plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind, ntt_plan **out_plan)
+{
+    if (n < 2 || (n & (n - 1)) != 0) return fail(NTT_ERR_INVALID, "ntt_negacyclic_plan_create: n must be a power of two >= 2");
+    return plan_create(ctx, p, n, batch, modmul_kind, true, out_plan);
+}
+
+static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind, bool negacyclic, ntt_plan **out_plan)
 {
     if (!ctx || !out_plan) return fail(NTT_ERR_INVALID, "ntt_plan_create: null argument");
     *out_plan = nullptr;
@@ -622,8 +656,9 @@ int ntt_plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind,
     if (n > (1 << 25)) return fail(NTT_ERR_UNSUPPORTED, "ntt_plan_create: n too large (transform length is capped at 2^26)");
     int logL = 1;
     while ((1u << logL) < 2u * (uint32_t)n) ++logL;
+    if (negacyclic) --logL;                               // x^n + 1: transform length n, 2n-th root psi
     const uint32_t L = 1u << logL;
-    if ((p - 1) % L != 0)
+    if ((p - 1) % (negacyclic ? 2 * (uint64_t)L : (uint64_t)L) != 0)
         return fail(NTT_ERR_UNSUPPORTED, "ntt_plan_create: p - 1 is not divisible by the transform length (p is not NTT-friendly for this n)");
     HIP_TRY(hipSetDevice(ctx->device));
 
@@ -636,6 +671,7 @@ int ntt_plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind,
     pl->L = L;
     pl->batch = batch;
     pl->kind = modmul_kind;
+    pl->negacyclic = negacyclic;
     pl->mp = make_mod_params(p);
     pl->lazy = p < (1u << 30);
     if (const char *e = std::getenv("NTT_AMD_FORCE_STRICT"))
@@ -672,7 +708,8 @@ int ntt_plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind,
         // kernels (roles do not overlap: F+R+I together take the sum of their solo times, see
         // DESIGN.md section 8), so the simpler path stays the default.  NTT_AMD_PIPE=1 enables it.
         pl->pipe = false;
-        if (const char *e = std::getenv("NTT_AMD_PIPE")) pl->pipe = e[0] == '1' && m == 1 && pl->level_log[0] >= 5;
+        if (const char *e = std::getenv("NTT_AMD_PIPE"))
+            pl->pipe = e[0] == '1' && m == 1 && pl->level_log[0] >= 5 && !negacyclic;
         const long slots = pl->pipe ? std::min<long>(3, (batch + chunk - 1) / chunk) : pl->lanes;
         int rc = pl->work0.ensure(per * chunk * slots);
         if (rc == NTT_OK) rc = pl->work1.ensure(per * chunk * slots);
@@ -689,14 +726,32 @@ int ntt_plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind,
 
 int ntt_plan_length(const ntt_plan *plan) { return plan ? (int)plan->L : 0; }
 
+static int multiply_entry(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab, size_t ab_stride,
+                          int batch, bool negacyclic);
+
 int ntt_poly_multiply_batched(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
                               size_t ab_stride, int batch)
 {
+    return multiply_entry(pl, a, b, ab, ab_stride, batch, false);
+}
+
+int ntt_negacyclic_multiply_batched(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *c,
+                                    size_t c_stride, int batch)
+{
+    return multiply_entry(pl, a, b, c, c_stride, batch, true);
+}
+
+static int multiply_entry(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab, size_t ab_stride,
+                          int batch, bool negacyclic)
+{
     if (!pl || !a || !b || !ab) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched: null argument");
+    if (pl->negacyclic != negacyclic)
+        return fail(NTT_ERR_INVALID, negacyclic ? "ntt_negacyclic_multiply_batched: the plan is not a negacyclic plan"
+                                                : "ntt_poly_multiply_batched: negacyclic plans multiply through ntt_negacyclic_multiply_batched");
     if (batch <= 0) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched: batch must be positive");
     if (batch > pl->batch) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched: batch exceeds the plan's capacity");
-    const size_t n = (size_t)pl->n, out_len = 2 * n - 1;
-    if (ab_stride < out_len) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched: ab_stride < 2n-1");
+    const size_t n = (size_t)pl->n, out_len = negacyclic ? n : 2 * n - 1;
+    if (ab_stride < out_len) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched: output row stride below the row length");
     ntt_ctx *cx = pl->ctx;
     std::lock_guard<std::mutex> lk(cx->mu);
     HIP_TRY(hipSetDevice(cx->device));

@@ -100,6 +100,10 @@ struct ntt_plan {
     void *tw_inv_plain = nullptr;       // innermost level with plain L^-1 (ntt_inverse)
     void *twA = nullptr, *twB = nullptr, *itwA = nullptr, *itwB = nullptr;
     void *small_w = nullptr, *small_iw = nullptr;
+    // negacyclic plans (products modulo x^n + 1, L = n): psi^i and psi^-i, psi = g^((p-1)/2n);
+    // small_itwist = psi^-i with the multiply scale folded in (L <= 4096 path)
+    bool negacyclic = false;
+    void *twist_fwd = nullptr, *twist_inv = nullptr, *small_itwist = nullptr;
     // by-value kernel constants, raw bytes of Roots64<MM> / tw_t
     std::vector<unsigned char> roots, iroots, scale_mul, scale_plain;
     std::vector<unsigned char> tw_in_fwd[8], tw_in_inv[8];   // per level with N1 >= 32 (col16 kernels)

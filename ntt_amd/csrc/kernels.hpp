@@ -34,6 +34,9 @@ struct ColArgs {
     int canon;                           // 1: final pass, store canonical residues
     Roots64<MM> roots;
     typename MM::tw_t tw_in[64];         // col16 kernels: inner twiddles w_N1^(+-r*ka), index r*16 + ka
+    // negacyclic products (x^n + 1): [L] table psi^(+-i); a forward pass multiplies its inputs by it,
+    // the final inverse pass its outputs.  nullptr for the ordinary (cyclic) transform.
+    const typename MM::tw_t *twist;
 };
 
 template <class MM>
@@ -65,6 +68,8 @@ struct SmallArgs {
     const typename MM::tw_t *w, *iw;     // w_L^j and w_L^-j, j < L/2
     typename MM::tw_t scale;             // L^-1 (times R for Montgomery's pointwise product)
     int mode;                            // 0 multiply, 1 forward (natural out), 2 inverse (natural in)
+    // negacyclic multiply (mode 0 only): psi^i, and psi^-i with `scale` folded in; nullptr otherwise
+    const typename MM::tw_t *twist, *itwist;
 };
 
 // One of the four CRT primes: Barrett constants plus the Shoup forms of 1 and 2^32 mod m.

@@ -41,6 +41,13 @@ __global__ void __launch_bounds__(256) col_kernel(const ColArgs<MM> a, const Mod
         if (HALF && i1 >= N1 / 2) x[i1] = 0;
         else x[i1] = buf_load(rin, voff + ((uint32_t)i1 << rowsh), 0);
     }
+    if (!INVERSE && a.twist) {                                    // negacyclic: x[i] * psi^i  (uniform branch)
+        const bufrsrc_t rtwist = make_buf(a.twist, (uint32_t)sizeof(tw_t) << a.logM);
+        const uint32_t toff = base * (uint32_t)sizeof(tw_t);
+#pragma unroll
+        for (int i1 = 0; i1 < N1; ++i1)
+            if (!(HALF && i1 >= N1 / 2)) x[i1] = O::mul_tw(x[i1], buf_load_tw<tw_t>(rtwist, toff, (uint32_t)i1 << twsh), m);
+    }
     if constexpr (INVERSE) {
         // inputs may be loose: every row is multiplied, except row 0 of an outer level
         x[0] = a.use_scale0 ? O::mul_tw(x[0], a.scale0, m) : O::tighten(x[0], m);
@@ -58,7 +65,14 @@ __global__ void __launch_bounds__(256) col_kernel(const ColArgs<MM> a, const Mod
     // inverse: non-final levels hand loose values to the next level; the final one canonicalises.
     // Stores beyond out_len are dropped by the range check.  (a.canon is uniform: a branch, not a
     // select per value.)
-    if (a.canon) {
+    if (INVERSE && a.canon && a.twist) {                          // negacyclic: result * psi^-i, canonical
+        const bufrsrc_t rtwist = make_buf(a.twist, (uint32_t)sizeof(tw_t) << a.logM);
+        const uint32_t toff = base * (uint32_t)sizeof(tw_t);
+#pragma unroll
+        for (int k1 = 0; k1 < N1; ++k1)
+            buf_store(O::canon(O::mul_tw(x[k1], buf_load_tw<tw_t>(rtwist, toff, (uint32_t)k1 << twsh), m), m), rout,
+                      voff + ((uint32_t)k1 << rowsh), 0);
+    } else if (a.canon) {
 #pragma unroll
         for (int k1 = 0; k1 < N1; ++k1)
             buf_store(O::canon(INVERSE ? O::tighten(x[k1], m) : x[k1], m), rout, voff + ((uint32_t)k1 << rowsh), 0);

@@ -62,6 +62,10 @@ __global__ void __launch_bounds__(256) small_kernel(const SmallArgs<MM> a, const
         for (uint32_t i = threadIdx.x; i < L; i += 256) {
             A[i] = i < a.in_len ? pa[i] : 0u;
             B[i] = i < a.in_len ? pb[i] : 0u;
+            if (a.twist) {                                  // negacyclic: operands times psi^i
+                A[i] = O::mul_tw(A[i], a.twist[i], m);
+                B[i] = O::mul_tw(B[i], a.twist[i], m);
+            }
         }
         __syncthreads();
         lds_dif<MM, LAZY>(A, a.logL, a.w, m);
@@ -70,7 +74,7 @@ __global__ void __launch_bounds__(256) small_kernel(const SmallArgs<MM> a, const
         __syncthreads();
         lds_dit<MM, LAZY>(A, a.logL, a.iw, m);
         for (uint32_t i = threadIdx.x; i < L && i < a.out_len; i += 256)
-            po[i] = csub(MM::mul_tw(A[i], a.scale, m), m.p);
+            po[i] = csub(MM::mul_tw(A[i], a.itwist ? a.itwist[i] : a.scale, m), m.p);
     } else if (a.mode == 1) {
         for (uint32_t i = threadIdx.x; i < L; i += 256) A[i] = pa[i];
         __syncthreads();

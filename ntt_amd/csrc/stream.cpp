@@ -173,6 +173,7 @@ extern "C" int ntt_poly_multiply_stream(ntt_plan *pl, const uint32_t *a, const u
 {
     if (!pl || !a || !b || !ab) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_stream: null argument");
     if (count == 0) return NTT_OK;
+    if (pl->negacyclic) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_stream: not for negacyclic plans");
     const size_t n = (size_t)pl->n, out_len = 2 * n - 1;
     if (ab_stride < out_len) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_stream: ab_stride < 2n-1");
     if (is_device_ptr(a) || is_device_ptr(b) || is_device_ptr(ab))

@@ -1,0 +1,159 @@
+"""GPU parity tests of the negacyclic product c = a * b mod (x^n + 1, p) (ntt_negacyclic_*) through the C ABI.
+
+The reference has no negacyclic routine, so nothing of its own pins this entry point.  Its definition is
+taken from the linear product the oracle restates and the reference's vectors pin:
+c[i] = ab[i] - ab[i + n] (mod p), with ab = orc.poly_multiply (oracle/ntt_oracle.c, main-montgomery.cc:317-351);
+plus a pure-Python schoolbook for tiny n and ring identities (x^n = -1) at every size.
+"""
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+P = 998244353            # lazy kernels ([0, 2p) ranges), 2-adicity 23
+P_STRICT = 1224736769    # > 2^30: strict kernels, 2-adicity 24
+P_C = 469762049          # 2-adicity 26
+
+
+@pytest.fixture(scope="module")
+def nt():
+    import ntt_amd
+    return ntt_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(nt):
+    c = nt.Context(0)
+    yield c
+    c.close()
+
+
+def rand(rng, shape, p):
+    return rng.integers(0, p, size=shape, dtype=np.int64).astype(np.uint32)
+
+
+def negacyclic_from_linear(a, b, p):
+    n = a.size
+    ab = np.asarray(orc.poly_multiply(a, b, p)).astype(np.int64)
+    lo = ab[:n].copy()
+    hi = np.zeros(n, dtype=np.int64)
+    hi[:n - 1] = ab[n:]
+    return ((lo - hi) % p).astype(np.uint32)
+
+
+def school_negacyclic(a, b, p):
+    n = len(a)
+    c = [0] * n
+    for i in range(n):
+        for j in range(n):
+            k = i + j
+            if k < n:
+                c[k] += int(a[i]) * int(b[j])
+            else:
+                c[k - n] -= int(a[i]) * int(b[j])
+    return np.array([v % p for v in c], dtype=np.uint32)
+
+
+@pytest.mark.parametrize("p", [P, P_STRICT])
+def test_negacyclic_tiny_schoolbook(nt, ctx, p):
+    rng = np.random.default_rng(p % 97)
+    for n in (2, 4, 8, 64):
+        a, b = rand(rng, n, p), rand(rng, n, p)
+        a[0] = p - 1
+        b[n - 1] = p - 1
+        for kind in (nt.MONTGOMERY, nt.BARRETT):
+            plan = ctx.negacyclic_plan(p, n, 1, kind)
+            assert plan.length == n
+            got = plan.multiply(a, b)[0]
+            plan.close()
+            assert np.array_equal(got, school_negacyclic(a, b, p)), (p, n, kind)
+
+
+# L = n: small path (<= 4096), one column level of 2 / 16 / 32 / 64 points, two levels (2^19)
+@pytest.mark.parametrize("n", [256, 4096, 8192, 65536, 131072, 262144, 524288])
+@pytest.mark.parametrize("p,kind", [(P, 0), (P_STRICT, 0), (P_C, 1)])
+def test_negacyclic_vs_linear_oracle(nt, ctx, n, p, kind):
+    rng = np.random.default_rng(n + p % 1000)
+    a, b = rand(rng, n, p), rand(rng, n, p)
+    a[-1] = p - 1
+    b[-1] = p - 1
+    plan = ctx.negacyclic_plan(p, n, 1, nt.MONTGOMERY if kind == 0 else nt.BARRETT)
+    got = plan.multiply(a, b)[0]
+    plan.close()
+    assert np.array_equal(got, negacyclic_from_linear(a, b, p))
+
+
+def test_negacyclic_ring_identities(ctx):
+    """x^k * a rotates a by k with a sign flip on wrap (x^n = -1); 1 is the unit; (p-1) negates."""
+    n, p = 65536, P
+    rng = np.random.default_rng(2)
+    a = rand(rng, n, p)
+    plan = ctx.negacyclic_plan(p, n, 1)
+    one = np.zeros(n, dtype=np.uint32)
+    one[0] = 1
+    assert np.array_equal(plan.multiply(a, one)[0], a)
+    for k in (1, 5, n - 1):
+        xk = np.zeros(n, dtype=np.uint32)
+        xk[k] = 1
+        want = np.concatenate([(p - a[n - k:].astype(np.int64)) % p, a[:n - k].astype(np.int64)]).astype(np.uint32)
+        assert np.array_equal(plan.multiply(a, xk)[0], want), k
+    neg = np.zeros(n, dtype=np.uint32)
+    neg[0] = p - 1
+    assert np.array_equal(plan.multiply(a, neg)[0], ((p - a.astype(np.int64)) % p).astype(np.uint32))
+    plan.close()
+
+
+def test_negacyclic_batched_device_resident(nt, ctx):
+    """RNS shape (BASELINE.json configs[3]): n = 2^16, a batch of device-resident pairs, row stride n + 3
+    (entries beyond n are not ours); several chunks and both lanes."""
+    import torch
+    n, B, p = 65536, 200, P_STRICT
+    rng = np.random.default_rng(9)
+    a, b = rand(rng, (B, n), p), rand(rng, (B, n), p)
+    da = torch.from_numpy(a.view(np.int32)).cuda()
+    db = torch.from_numpy(b.view(np.int32)).cuda()
+    out = torch.full((B, n + 3), -3, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    plan = ctx.negacyclic_plan(p, n, B)
+    plan.multiply(da, db, out=out, batch=B, out_stride=n + 3)
+    ctx.synchronize()
+    got = out.cpu().numpy()
+    assert (got[:, n:] == -3).all()
+    for i in (0, 1, 47, 48, 99, 199):
+        assert np.array_equal(got[i, :n].view(np.uint32), negacyclic_from_linear(a[i], b[i], p)), i
+    # linearity over the whole batch: (a + a') * b = a*b + a'*b in the ring
+    s = ((a[:100].astype(np.int64) + a[100:].astype(np.int64)) % p).astype(np.uint32)
+    ds = torch.from_numpy(s.view(np.int32)).cuda()
+    out2 = torch.zeros((100, n), dtype=torch.int32, device="cuda")
+    db2 = db[:100].contiguous()
+    torch.cuda.synchronize()
+    plan.multiply(ds, db2, out=out2, batch=100)
+    plan.multiply(da[100:].contiguous(), db2, out=out[:100], batch=100, out_stride=n + 3)
+    ctx.synchronize()
+    lhs = out2.cpu().numpy().view(np.uint32).astype(np.int64)
+    r1 = got[:100, :n].view(np.uint32).astype(np.int64)
+    r2 = out.cpu().numpy()[:100, :n].view(np.uint32).astype(np.int64)
+    assert np.array_equal(lhs, (r1 + r2) % p)
+    plan.close()
+
+
+def test_negacyclic_errors(nt, ctx):
+    with pytest.raises(nt.NttError):
+        ctx.negacyclic_plan(P, 1000)                      # not a power of two
+    with pytest.raises(nt.NttError):
+        ctx.negacyclic_plan(P, 1 << 23)                   # needs 2^24 | p - 1
+    plan = ctx.negacyclic_plan(P, 64, 2)
+    lin = ctx.plan(P, 64, 2)
+    a = np.zeros((2, 64), dtype=np.uint32)
+    with pytest.raises(nt.NttError):                      # entry points do not mix
+        nt._check(nt._lib.ntt_poly_multiply_batched(plan._h, a.ctypes.data, a.ctypes.data,
+                                                    np.zeros((2, 127), dtype=np.uint32).ctypes.data, 127, 2))
+    with pytest.raises(nt.NttError):
+        nt._check(nt._lib.ntt_negacyclic_multiply_batched(lin._h, a.ctypes.data, a.ctypes.data,
+                                                          np.zeros((2, 64), dtype=np.uint32).ctypes.data, 64, 2))
+    with pytest.raises(nt.NttError):
+        plan.multiply(a, a, out=np.zeros((2, 32), dtype=np.uint32), out_stride=32)
+    plan.close()
+    lin.close()
