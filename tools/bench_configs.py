@@ -69,9 +69,11 @@ def main():
     qab = np.zeros((B, 2 * n - 1), dtype=np.uint32)
     for name, (xa_, xb_, xo_) in (("pinned", (pa, pb, pab)), ("pageable", (qa, qb, qab))):
         plan.multiply_stream(xa_[:128], xb_[:128], out=xo_[:128])
-        t0 = time.perf_counter()
-        plan.multiply_stream(xa_, xb_, out=xo_)
-        dt = time.perf_counter() - t0
+        dt = 1e9
+        for _ in range(2):                                   # the first pass also faults in the output pages
+            t0 = time.perf_counter()
+            plan.multiply_stream(xa_, xb_, out=xo_)
+            dt = min(dt, time.perf_counter() - t0)
         print(json.dumps({"config": "1 streamed from %s HOST arrays (ntt_poly_multiply_stream, 1024 products)" % name,
                           "poly_mults_per_s": B / dt, "GBps_each_way_over_pcie": B * (8 * n) / dt / 1e9}), flush=True)
     assert np.array_equal(pab, qab)
@@ -153,6 +155,26 @@ def main():
     print(json.dumps({"config": "4: RNS batch n=2^16, 32 limbs x 256 pairs (strict [0,p) kernels, p > 2^30), one GPU",
                       "ms_per_batch": dt * 1e3, "poly_mults_per_s": limbs * per / dt}), flush=True)
     for pl in plans:
+        pl.close()
+
+    # ---- config 4 in the ring FHE workloads use: negacyclic products mod (x^n + 1), same shape
+    nplans = [ctx.negacyclic_plan(p, n, per, ntt_amd.MONTGOMERY) for p in primes]
+    nout = torch.zeros((per, n), dtype=torch.int32, device="cuda")
+
+    def neg_step():
+        for pl in nplans:
+            pl.multiply(xa, xb, out=nout, batch=per)
+
+    neg_step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        neg_step()
+    sync()
+    dt = (time.perf_counter() - t0) / reps
+    print(json.dumps({"config": "4 negacyclic (x^n + 1): n=2^16, 32 limbs x 256 pairs, one transform of length n per operand",
+                      "ms_per_batch": dt * 1e3, "poly_mults_per_s": limbs * per / dt}), flush=True)
+    for pl in nplans:
         pl.close()
 
     # ---- config 5 ------------------------------------------------------------------------------
