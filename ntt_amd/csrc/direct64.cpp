@@ -33,7 +33,8 @@ struct ntt_plan64 {
     int nlevels = 0;
     int level_log[8] = {0}, level_logM[8] = {0};
     uint64_t *tw_fwd[8] = {nullptr}, *tw_inv[8] = {nullptr};
-    uint64_t *row_w = nullptr, *row_iw = nullptr;
+    uint64_t *row_w = nullptr, *row_iw = nullptr;             // lds64_kernel (L <= 4096)
+    uint64_t *twA = nullptr, *twB = nullptr, *itwA = nullptr, *itwB = nullptr;   // row64_mul_kernel
     Roots16x64 roots{}, iroots{};
     uint64_t scale = 0;                     // L^-1 * R (cancels the pointwise R^-1), Montgomery form
     DeviceBuffer work0, work1, stage_a, stage_b, stage_out;
@@ -141,6 +142,15 @@ int build_tables(ntt_plan64 *pl)
         if ((rc = upload(pl, iw, &pl->row_iw))) return rc;
     }
     if (pl->nlevels == 0) return NTT_OK;
+    {   // 4096-point row kernel: pass twiddles w_4096^(k*t), w_256^(k*i) and their inverses
+        const uint64_t w4096 = powmod(wL, L / kRowLen, p), iw4096 = powmod(iwL, L / kRowLen, p);
+        const uint64_t w256 = powmod(w4096, 16, p), iw256 = powmod(iw4096, 16, p);
+        int rc = upload(pl, power_table(w4096, 16, 256, 1, mp), &pl->twA);
+        if (!rc) rc = upload(pl, power_table(w256, 16, 16, 1, mp), &pl->twB);
+        if (!rc) rc = upload(pl, power_table(iw4096, 16, 256, 1, mp), &pl->itwA);
+        if (!rc) rc = upload(pl, power_table(iw256, 16, 16, 1, mp), &pl->itwB);
+        if (rc) return rc;
+    }
     const uint64_t w16 = powmod(wL, L / 16, p), iw16 = powmod(iwL, L / 16, p);
     uint64_t c = 1, ic = 1;
     for (int j = 0; j < 8; ++j) {
@@ -214,15 +224,12 @@ int multiply_device(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64
     }
     // rows: forward a, forward b, pointwise, inverse
     {
-        Lds64Args r{};
+        Row64Args r{};
         r.a = w0; r.b = w1; r.out = w0;
-        r.in_stride = L; r.out_stride = L;
-        r.in_len = L; r.out_len = L;
-        r.blocks_per_row = L >> kRowLog; r.logLen = kRowLog;
-        r.w = pl->row_w; r.iw = pl->row_iw;
-        r.use_scale = 0; r.canon = 0; r.mode = 0;
+        r.twA = pl->twA; r.twB = pl->twB; r.itwA = pl->itwA; r.itwB = pl->itwB;
+        r.roots = pl->roots; r.iroots = pl->iroots;
         cx->begin(K_LDS64);
-        launch_lds64(r, pl->mp, (unsigned)batch * (L >> kRowLog), s);
+        launch_row64_mul(r, pl->mp, (unsigned)batch * (L >> kRowLog), s);
         cx->end();
     }
     // inverse column levels, innermost first; the outermost writes the caller's ab

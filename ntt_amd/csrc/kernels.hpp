@@ -146,6 +146,14 @@ struct Lds64Args {
     uint64_t scale;
     int use_scale, canon, mode;          // mode 0 multiply, 1 forward, 2 inverse
 };
+struct Row64Args {
+    const uint64_t *a, *b;               // [rows][4096]
+    uint64_t *out;
+    const uint64_t *twA, *twB;           // forward [16][256], [16][16], Montgomery form
+    const uint64_t *itwA, *itwB;         // inverse
+    Roots16x64 roots, iroots;
+};
+void launch_row64_mul(const Row64Args &a, const ModParams64 &mp, unsigned rows, hipStream_t s);
 void launch_col64(int logN1, bool inverse, bool half_in, const Col64Args &a, const ModParams64 &mp,
                   unsigned cols_per_row, unsigned batch, unsigned nops, hipStream_t s);
 void launch_lds64(const Lds64Args &a, const ModParams64 &mp, unsigned blocks, hipStream_t s);

@@ -10,10 +10,11 @@
 //   = T_hi + mulhi(q, p) + (T_lo != 0)        (the low words cancel to exactly 0 or 2^64)
 //
 // Same decomposition as the 32-bit path: column levels of N1 <= 16 points in
-// registers with the 4-step twiddle from an HBM table, rows of 4096 points in a 32 KiB LDS tile.
-// The row transform is radix-2 in LDS: decimation in frequency forward (natural in, bit-reversed
-// out), decimation in time inverse (bit-reversed in, natural out), pointwise product in between --
-// no reordering pass.
+// registers with the 4-step twiddle from an HBM table, rows of 4096 points as three radix-16
+// register passes around a 34 KiB LDS tile (row64_mul_kernel).  Transforms of L <= 4096 run in
+// lds64_kernel: radix-2 in LDS, decimation in frequency forward (natural in, bit-reversed out),
+// decimation in time inverse (bit-reversed in, natural out), pointwise product in between.  Neither
+// needs a reordering pass.
 #include "kernels.hpp"
 
 namespace ntt {
@@ -233,6 +234,94 @@ __global__ void __launch_bounds__(256) lds64_kernel(const Lds64Args a, const Mod
         if (a.canon) v = M64::canon(v, m);
         if ((off + i) < out_len) po[i] = v;
     }
+}
+
+// ---- 4096-point rows in registers: 4096 = 16 * 16 * 16 -----------------------------------------------------
+// Same three-pass structure and index maps as the 32-bit row kernel (row_body.hpp): thread t of 256 holds
+// 16 points, runs a 16-point register transform, multiplies by the pass twiddle and exchanges through a
+// padded LDS tile (P1, P2 as there, in units of 8-byte words).  On exit of row64_forward x[k] is the
+// spectrum at position 16 t + k of a fixed digit-reversed order, which row64_inverse consumes.
+constexpr int kRow64Words = kRowLen + kRowLen / 16;          // 4352 x 8 B = 34 KiB
+
+__device__ __forceinline__ uint32_t Q1(uint32_t i) { return i + ((i >> 8) << 4); }
+__device__ __forceinline__ uint32_t Q2(uint32_t i) { return i + (i >> 4); }
+
+__device__ __forceinline__ void row64_forward(uint64_t (&x)[16], uint64_t *lds, const uint32_t t, const Row64Args &a,
+                                              const ModParams64 &m)
+{
+    reg_ntt64<4, false>(x, a.roots, m);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) x[k] = M64::mulw(x[k], a.twA[k * 256 + t], m);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[Q1(k * 256 + t)] = x[k];
+    __syncthreads();
+    const uint32_t b = t >> 4, i = t & 15;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = lds[Q1(b * 256 + j * 16 + i)];
+    __syncthreads();
+    reg_ntt64<4, false>(x, a.roots, m);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) x[k] = M64::mulw(x[k], a.twB[k * 16 + i], m);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[Q2(b * 256 + k * 16 + i)] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = lds[Q2(t * 16 + j)];
+    __syncthreads();
+    reg_ntt64<4, false>(x, a.roots, m);
+}
+
+__device__ __forceinline__ void row64_inverse(uint64_t (&x)[16], uint64_t *lds, const uint32_t t, const Row64Args &a,
+                                              const ModParams64 &m)
+{
+    reg_ntt64<4, false>(x, a.iroots, m);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) lds[Q2(t * 16 + j)] = x[j];
+    __syncthreads();
+    const uint32_t b = t >> 4, i = t & 15;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[Q2(b * 256 + k * 16 + i)];
+    __syncthreads();
+#pragma unroll
+    for (int k = 1; k < 16; ++k) x[k] = M64::mulw(x[k], a.itwB[k * 16 + i], m);
+    reg_ntt64<4, false>(x, a.iroots, m);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) lds[Q1(b * 256 + j * 16 + i)] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[Q1(k * 256 + t)];
+    __syncthreads();
+#pragma unroll
+    for (int k = 1; k < 16; ++k) x[k] = M64::mulw(x[k], a.itwA[k * 256 + t], m);
+    reg_ntt64<4, false>(x, a.iroots, m);
+}
+
+// Fused multiply of one 4096-point row: forward a, forward b, pointwise, inverse (in place on a's row).
+__global__ void __launch_bounds__(256) row64_mul_kernel(const Row64Args a, const ModParams64 m)
+{
+    __shared__ uint64_t lds[kRow64Words];
+    const uint32_t t = threadIdx.x;
+    const size_t row = (size_t)blockIdx.x * kRowLen;
+    const uint64_t *__restrict__ pa = a.a + row;
+    const uint64_t *__restrict__ pb = a.b + row;
+    uint64_t xa[16], xb[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xa[j] = pa[t + 256 * j];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xb[j] = pb[t + 256 * j];
+    row64_forward(xa, lds, t, a, m);
+    row64_forward(xb, lds, t, a, m);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) xa[k] = M64::mulw(xa[k], xb[k], m);      // REDC(a*b); R^-1 folded into the scale
+    row64_inverse(xa, lds, t, a, m);
+    uint64_t *__restrict__ po = a.out + row;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) po[t + 256 * j] = xa[j];
+}
+
+void launch_row64_mul(const Row64Args &a, const ModParams64 &mp, unsigned rows, hipStream_t s)
+{
+    hipLaunchKernelGGL(row64_mul_kernel, dim3(rows), dim3(256), 0, s, a, mp);
 }
 
 void launch_lds64(const Lds64Args &a, const ModParams64 &mp, unsigned blocks, hipStream_t s)
