@@ -49,10 +49,29 @@ def cpu_baseline(n, p, threads, budget_s):
         _, s = orc.poly_multiply_omp(a, b, p, threads=threads)
         secs += s
         reps += 1
-    return {"value": reps / secs, "unit": "poly-mults/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} products of n={n}, p={p} (oracle port of main-openmp.cc:678-692, "
-                      f"timer between its Start/End stamps), {threads} OpenMP threads",
-            "ms_per_product": 1e3 * secs / reps}
+    out = {"value": reps / secs, "unit": "poly-mults/s", "cores": threads, "kind": "port",
+           "sample": f"{reps} products of n={n}, p={p} (oracle port of main-openmp.cc:678-692, "
+                     f"timer between its Start/End stamps), {threads} OpenMP threads",
+           "ms_per_product": 1e3 * secs / reps}
+    # also the reference's own hard-coded num_threads(8) and the single-thread
+    # Montgomery / Barrett harness bodies (main-montgomery.cc:317-351, main-barrett.cc:249-282); a few
+    # products each, whole call timed
+    others = {}
+    s8, r8 = 0.0, 0
+    for _ in range(10):
+        _, s = orc.poly_multiply_omp(a, b, p, threads=min(8, threads))
+        s8 += s
+        r8 += 1
+    others[f"openmp_{min(8, threads)}_threads_ms"] = 1e3 * s8 / r8
+    a32, b32 = a.astype(np.uint32), b.astype(np.uint32)
+    for kind in ("mont", "barrett"):
+        orc.poly_multiply(a32, b32, p, kind=kind)
+        t1 = time.time()
+        for _ in range(3):
+            orc.poly_multiply(a32, b32, p, kind=kind)
+        others[f"single_thread_{kind}_ms"] = 1e3 * (time.time() - t1) / 3
+    out["others_ms_per_product"] = others
+    return out
 
 
 def main():
