@@ -93,12 +93,17 @@ int main(int argc, char **argv)
             }
             std::vector<uint32_t> a32(n), b32(n), ab32((size_t)2 * n - 1);
             for (int i = 0; i < n; ++i) { a32[i] = (uint32_t)a[i]; b32[i] = (uint32_t)b[i]; }
-            uint32_t *da, *db, *dab;
-            (void)hipMalloc(&da, (size_t)n * 4);
-            (void)hipMalloc(&db, (size_t)n * 4);
-            (void)(void)hipMalloc(&dab, ab32.size() * 4);
-            (void)hipMemcpy(da, a32.data(), (size_t)n * 4, hipMemcpyHostToDevice);
-            (void)hipMemcpy(db, b32.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+            uint32_t *da = nullptr, *db = nullptr, *dab = nullptr;
+            if (hipMalloc(&da, (size_t)n * 4) != hipSuccess || hipMalloc(&db, (size_t)n * 4) != hipSuccess ||
+                hipMalloc(&dab, ab32.size() * 4) != hipSuccess ||
+                hipMemcpy(da, a32.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(db, b32.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) {
+                std::fprintf(stderr, "case %d: device allocation or copy failed\n", id);
+                (void)hipFree(da); (void)hipFree(db); (void)hipFree(dab);
+                ntt_plan_destroy(plan);
+                ++bad;
+                continue;
+            }
             for (int e = 0; e < epochs + 1; ++e) {      // epoch 0 warms up (module load), untimed
                 auto t0 = std::chrono::high_resolution_clock::now();
                 rc = ntt_poly_multiply_batched(plan, da, db, dab, ab32.size(), 1);
@@ -107,7 +112,10 @@ int main(int argc, char **argv)
                 if (rc != NTT_OK) break;
                 if (e > 0) total_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
             }
-            (void)hipMemcpy(ab32.data(), dab, ab32.size() * 4, hipMemcpyDeviceToHost);
+            if (rc == NTT_OK && hipMemcpy(ab32.data(), dab, ab32.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+                std::fprintf(stderr, "case %d: copy back failed\n", id);
+                rc = NTT_ERR_HIP;
+            }
             (void)hipFree(da); (void)hipFree(db); (void)hipFree(dab);
             ntt_plan_destroy(plan);
             for (size_t i = 0; i < ab32.size(); ++i) ab[i] = ab32[i];

@@ -606,3 +606,39 @@ def test_kernel_timing(ctx):
     assert t["col_fwd"][1] == 1 and t["row_mul"][1] == 1 and t["col_inv"][1] == 1
     assert t["row_mul"][0] > 0
     plan.close()
+
+
+def test_concurrent_callers(nt, ctx):
+    """Calls on one handle are serialised by its mutex; separate contexts run side by side.  Four Python
+    threads (ctypes drops the GIL inside the C ABI) multiply through a shared context and through a second
+    one at the same time; every result must be the oracle's."""
+    import threading
+    n, p, B = 8192, 998244353, 4
+    rng = np.random.default_rng(21)
+    jobs = []
+    for t in range(4):
+        a, b = rand_poly(rng, n, p, B), rand_poly(rng, n, p, B)
+        jobs.append((a, b, [orc.poly_multiply(a[i], b[i], p) for i in range(B)]))
+    ctx2 = nt.Context(0)
+    plans = [ctx.plan(p, n, B), ctx.plan(p, n, B, nt.BARRETT), ctx2.plan(p, n, B), ctx2.plan(p, n, B)]
+    errors = []
+
+    def work(t):
+        try:
+            for _ in range(10):
+                got = plans[t].multiply(jobs[t][0], jobs[t][1])
+                for i in range(B):
+                    if not np.array_equal(got[i], jobs[t][2][i]):
+                        errors.append((t, i))
+        except Exception as e:                      # pragma: no cover
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for pl in plans:
+        pl.close()
+    ctx2.close()
+    assert not errors, errors
