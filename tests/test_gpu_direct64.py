@@ -4,9 +4,10 @@ What pins it: the big-integer golden vectors of tests/golden/crt_vectors.npz (p 
 the modulus of the reference's fifth case), the 4-prime CRT oracle (oracle/ntt_oracle.c,
 orc_poly_multiply_crt, restating main-openmp.cc:693-711) wherever n * p^2 stays below the product of
 its primes, Python big-integer schoolbook products for small n, and -- for primes near 2^62, where
-no oracle applies -- the evaluation identity A(x) * B(x) = AB(x) (mod p).  The reference itself
-holds no data for a single 64-bit modulus (its `power` is 32-bit): parity of this path
-is unpinned by the reference's own files.
+no oracle applies -- the evaluation identity A(x) * B(x) = AB(x) (mod p).  The reference's own
+cases nttdata/0-3 (32-bit primes) run through the 64-bit lanes too and must reproduce its golden
+outputs; for a modulus above 32 bits the reference holds no data (its `power` is 32-bit),
+so that range is pinned by the big-integer vectors and the CRT oracle only.
 """
 import numpy as np
 import pytest
@@ -172,3 +173,14 @@ def test_direct64_errors(nt, ctx):
     with pytest.raises(nt.NttError):
         plan.multiply(a, a, batch=3)
     plan.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_direct64_reference_golden(ctx, nttdata, cid):
+    """The reference's own cases (nttdata/<id>.in/.out, 32-bit primes) through the 64-bit lanes: a third,
+    independent route to the golden outputs."""
+    n, p, a, b, ab = nttdata[cid]
+    plan = ctx.plan64(p, n)
+    got = plan.multiply(a.astype(np.uint64), b.astype(np.uint64))[0]
+    plan.close()
+    assert np.array_equal(got, ab.astype(np.uint64))

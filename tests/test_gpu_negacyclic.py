@@ -1,9 +1,10 @@
 """GPU parity tests of the negacyclic product c = a * b mod (x^n + 1, p) (ntt_negacyclic_*) through the C ABI.
 
-The reference has no negacyclic routine, so nothing of its own pins this entry point.  Its definition is
-taken from the linear product the oracle restates and the reference's vectors pin:
-c[i] = ab[i] - ab[i + n] (mod p), with ab = orc.poly_multiply (oracle/ntt_oracle.c, main-montgomery.cc:317-351);
-plus a pure-Python schoolbook for tiny n and ring identities (x^n = -1) at every size.
+The reference has no negacyclic routine.  The definition is taken from the linear product its vectors pin:
+c[i] = ab[i] - ab[i + n] (mod p) -- with ab the reference's own golden outputs (nttdata/<id>.out,
+test_negacyclic_from_reference_golden) and, at other sizes and primes, ab = orc.poly_multiply
+(oracle/ntt_oracle.c, main-montgomery.cc:317-351); plus a pure-Python schoolbook for tiny n and ring
+identities (x^n = -1).
 """
 import numpy as np
 import pytest
@@ -157,3 +158,19 @@ def test_negacyclic_errors(nt, ctx):
         plan.multiply(a, a, out=np.zeros((2, 32), dtype=np.uint32), out_stride=32)
     plan.close()
     lin.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_negacyclic_from_reference_golden(nt, ctx, nttdata, cid, kind):
+    """Anchored on the reference's own vectors: the golden linear product ab of nttdata/<id>.out reduced
+    modulo x^n + 1 (c[i] = ab[i] - ab[i+n]) must equal the negacyclic product of the golden inputs."""
+    n, p, a, b, ab = nttdata[cid]
+    ab = ab.astype(np.int64)
+    hi = np.zeros(n, dtype=np.int64)
+    hi[:n - 1] = ab[n:]
+    want = ((ab[:n] - hi) % p).astype(np.uint32)
+    plan = ctx.negacyclic_plan(p, n, 1, nt.MONTGOMERY if kind == 0 else nt.BARRETT)
+    got = plan.multiply(a.astype(np.uint32), b.astype(np.uint32))[0]
+    plan.close()
+    assert np.array_equal(got, want)
