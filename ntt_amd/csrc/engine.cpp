@@ -418,8 +418,78 @@ int multiply_device_any(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint
                                              : multiply_device<Barrett32>(pl, a, b, ab, ab_stride, batch);
 }
 
+// Tile description for the LDS-staged digit reversal: dst[R(i)] = src[i] where i has the bit fields
+// `w` (most significant first) and R reverses their order.  False if no tile of the wanted shape exists
+// (never for L >= 8192; the caller then falls back to the plain kernel).
+static bool make_perm_tile(const std::vector<int> &w, int logL, PermTileArgs &pa)
+{
+    const int nf = (int)w.size();
+    if (nf > 8) return false;
+    // field f occupies bits [lo[f], lo[f] + w[f]) of i and [klo[f], ...) of R(i)
+    std::vector<int> lo(nf), klo(nf);
+    int acc = logL;
+    for (int f = 0; f < nf; ++f) { acc -= w[f]; lo[f] = acc; }
+    acc = 0;
+    for (int f = 0; f < nf; ++f) { klo[f] = acc; acc += w[f]; }
+    if (acc != logL) return false;
+    pa.logL = logL;
+    pa.n_rev = nf;
+    for (int f = 0; f < nf; ++f) pa.rev[f] = BitRun{lo[f], w[f], klo[f]};
+    // 32 x 64 tiles (128-byte output runs, 256-byte input runs) measured best at L = 2^26: 217 us per
+    // array; 64 x 128 tiles 282 us (profiles/sweep_permute_r01e.txt)
+    int a = 5, b = 6;
+    // bits of i that R sends to output bits [0, a): they must not meet the low b bits of i
+    for (;; ) {
+        uint32_t tmask = 0;
+        pa.n_top = 0;
+        for (int f = 0; f < nf && klo[f] < a; ++f) {
+            const int width = std::min(w[f], a - klo[f]);
+            pa.top[pa.n_top++] = BitRun{klo[f], width, lo[f]};
+            tmask |= ((1u << width) - 1u) << lo[f];
+        }
+        const uint32_t lmask = (1u << b) - 1u;
+        if ((tmask & lmask) == 0) {
+            // remaining bits of i, lowest first, as runs fed from the block index
+            uint32_t rest = ~(tmask | lmask) & (logL == 32 ? 0xffffffffu : ((1u << logL) - 1u));
+            pa.n_mid = 0;
+            int from = 0;
+            for (int bit = 0; bit < logL; ) {
+                if (!((rest >> bit) & 1u)) { ++bit; continue; }
+                int width = 0;
+                while (bit + width < logL && ((rest >> (bit + width)) & 1u)) ++width;
+                if (pa.n_mid >= 12) return false;
+                pa.mid[pa.n_mid++] = BitRun{from, width, bit};
+                from += width;
+                bit += width;
+            }
+            pa.a = a;
+            pa.b = b;
+            return from == logL - a - b;
+        }
+        if (b > 5) --b;
+        else if (a > 5) --a;
+        else return false;                                   // tile sizes below 2^10 have no kernel
+    }
+}
+
 static void permute_pass(ntt_plan *pl, const uint32_t *src, uint32_t *dst, bool to_natural, unsigned batch)
 {
+    {
+        std::vector<int> w;
+        for (int j = 0; j < pl->nlevels; ++j) w.push_back(pl->level_log[j]);
+        w.push_back(4); w.push_back(4); w.push_back(4);
+        if (!to_natural) std::reverse(w.begin(), w.end());       // dst[pos] = src[k]: the fields of k, top first
+        PermTileArgs ta{};
+        if (make_perm_tile(w, pl->logL, ta)) {
+            ta.src = src; ta.dst = dst;
+            ta.canon_p = (to_natural && pl->lazy) ? pl->p : 0;   // forward spectrum leaves the rows in [0, 2p)
+            ntt_ctx *cx = pl->ctx;
+            cx->begin(K_PERMUTE);
+            launch_permute_tiled(ta, batch, cx->cur);
+            cx->end();
+            return;
+        }
+    }
     PermArgs pa{};
     pa.src = src; pa.dst = dst;
     pa.logL = pl->logL;

@@ -111,6 +111,26 @@ struct PermArgs {
 };
 void launch_permute(const PermArgs &pa, unsigned batch, hipStream_t s);
 
+// Tiled form of the same permutation: dst[R(i)] = src[i], R = reversal of the ORDER of the bit fields
+// of i (each field keeps its bits).  A workgroup moves a tile of 2^(a+b) elements through LDS: the low
+// b bits of i (one contiguous input run per value of the rest) times the a bits of i that R sends to
+// the low a bits of the output index (one contiguous output run per value of the rest).  Bit moves are
+// given as runs {from, width, to}: x' |= ((x >> from) & (2^width - 1)) << to.
+struct BitRun {
+    int from, width, to;
+};
+struct PermTileArgs {
+    const uint32_t *src;
+    uint32_t *dst;
+    int logL, a, b;
+    int n_rev, n_top, n_mid;
+    BitRun rev[8];                       // i -> R(i)
+    BitRun top[8];                       // tile row index (= low a bits of R(i)) -> its bits in i
+    BitRun mid[12];                      // block index -> the bits of i outside the tile
+    uint32_t canon_p;                    // != 0: values are in [0, 2p), store canonical residues
+};
+void launch_permute_tiled(const PermTileArgs &pa, unsigned batch, hipStream_t s);
+
 void launch_crt_reduce(const uint64_t *x, uint32_t *out, size_t n, const CrtPrime &c, hipStream_t s);
 void launch_crt_merge(const uint32_t *const res[4], uint64_t *out, size_t n, const CrtConsts &cc,
                       hipStream_t s);

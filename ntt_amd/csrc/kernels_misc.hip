@@ -133,6 +133,63 @@ void launch_permute(const PermArgs &pa, unsigned batch, hipStream_t s)
     hipLaunchKernelGGL(permute_kernel, dim3((1u << pa.logL) / 256, batch), dim3(256), 0, s, pa);
 }
 
+// Tiled digit reversal (see PermTileArgs): both the loads and the stores of a workgroup are contiguous
+// runs (2^b and 2^a elements), the reshuffle happens in a padded LDS tile.  The plain kernel above
+// stores 4-byte words 2^(logL - w1) elements apart: 1.47 ms per 2^26-point array against 0.22 ms here.
+template <int N>
+__device__ __forceinline__ uint32_t apply_runs(uint32_t x, const BitRun (&r)[N], int n)
+{
+    uint32_t y = 0;
+    for (int j = 0; j < n; ++j) y |= ((x >> r[j].from) & ((1u << r[j].width) - 1u)) << r[j].to;
+    return y;
+}
+
+template <int LOGT>                                                       // tile of 2^LOGT elements
+__global__ void __launch_bounds__(256) permute_tiled_kernel(const PermTileArgs pa)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
+    constexpr int PER = (1 << LOGT) / 256;                                 // elements per thread
+    const size_t row = (size_t)blockIdx.y << pa.logL;
+    const uint32_t base = apply_runs(blockIdx.x, pa.mid, pa.n_mid);        // bits of i outside the tile
+    const uint32_t nb = 1u << pa.b, pitch = nb + 1;
+    uint32_t v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {                                        // contiguous input runs, all loads in flight
+        const uint32_t e = threadIdx.x + 256u * j;
+        const uint32_t l = e & (nb - 1), t = e >> pa.b;
+        v[j] = pa.src[row + (base | apply_runs(t, pa.top, pa.n_top) | l)];
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const uint32_t e = threadIdx.x + 256u * j;
+        tile[(e >> pa.b) * pitch + (e & (nb - 1))] = v[j];
+    }
+    __syncthreads();
+    const uint32_t na = 1u << pa.a;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {                                        // contiguous output runs
+        const uint32_t e = threadIdx.x + 256u * j;
+        const uint32_t t = e & (na - 1), l = e >> pa.a;
+        const uint32_t i = base | apply_runs(t, pa.top, pa.n_top) | l;
+        uint32_t x = tile[t * pitch + l];
+        if (pa.canon_p) x = csub(x, pa.canon_p);
+        pa.dst[row + apply_runs(i, pa.rev, pa.n_rev)] = x;
+    }
+}
+
+void launch_permute_tiled(const PermTileArgs &pa, unsigned batch, hipStream_t s)
+{
+    const size_t lds = (size_t)((1u << pa.b) + 1) * (1u << pa.a) * sizeof(uint32_t);
+    const dim3 grid(1u << (pa.logL - pa.a - pa.b), batch);
+    switch (pa.a + pa.b) {
+    case 10: hipLaunchKernelGGL(permute_tiled_kernel<10>, grid, dim3(256), lds, s, pa); break;
+    case 11: hipLaunchKernelGGL(permute_tiled_kernel<11>, grid, dim3(256), lds, s, pa); break;
+    case 12: hipLaunchKernelGGL(permute_tiled_kernel<12>, grid, dim3(256), lds, s, pa); break;
+    case 13: hipLaunchKernelGGL(permute_tiled_kernel<13>, grid, dim3(256), lds, s, pa); break;
+    default: break;                                                        // make_perm_tile only builds these
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // CRT kernels.  Replace CRT_parallel's implicit input reduction (main-openmp.cc:426-427) and
 // CRT_combine_parallel (main-openmp.cc:468-485).  The reference sums r_k * inv_k * (M/m_k) mod M
