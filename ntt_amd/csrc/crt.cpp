@@ -117,15 +117,30 @@ extern "C" int ntt_crt_multiply(ntt_ctx *ctx, const uint64_t *a, const uint64_t 
     uint32_t *ra = static_cast<uint32_t *>(w.ra.ptr), *rb = static_cast<uint32_t *>(w.rb.ptr);
     uint32_t *res = static_cast<uint32_t *>(w.res.ptr);
     const uint32_t *rows[4];
-    for (int k = 0; k < 4; ++k) {
-        ctx->begin(K_CRT_REDUCE);
-        launch_crt_reduce(da, ra + k * N, N, cc.prime[k], ctx->stream);
-        launch_crt_reduce(db, rb + k * N, N, cc.prime[k], ctx->stream);
-        ctx->end();
+    ctx->begin(K_CRT_REDUCE);                              // both operands, all four primes: one launch
+    launch_crt_reduce_all(da, db, ra, rb, N, N, cc, ctx->stream);
+    ctx->end();
+    // The four residue products are independent (the reference gives each its own OpenMP thread,
+    // main-openmp.cc:697, or MPI rank): primes 1 and 3 run on the context's second lane beside primes 0
+    // and 2 -- the kernels of a single product are too small to fill the chip, so the two chains overlap.
+    hipStream_t main_stream = ctx->stream;
+    const bool two = ctx->nlanes > 1 && ctx->lane[1] && ctx->lane_limit != 1;
+    if (two) {
+        HIP_TRY(hipEventRecord(ctx->fork_ev, main_stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->lane[1], ctx->fork_ev, 0));
+    }
+    for (int k = 0; k < 4 && !rc; ++k) {
+        ctx->stream = (two && (k & 1)) ? ctx->lane[1] : main_stream;     // the plan's launches follow ctx->stream
         rc = multiply_device_any(w.plans[k], ra + k * N, rb + k * N, res + k * out_len, out_len, 1);
-        if (rc) return rc;
         rows[k] = res + k * out_len;
     }
+    ctx->stream = main_stream;
+    ctx->cur = main_stream;
+    if (two) {
+        HIP_TRY(hipEventRecord(ctx->lane_done[1], ctx->lane[1]));
+        HIP_TRY(hipStreamWaitEvent(main_stream, ctx->lane_done[1], 0));
+    }
+    if (rc) return rc;
     ctx->begin(K_CRT_MERGE);
     launch_crt_merge(rows, dout, out_len, cc, ctx->stream);
     ctx->end();

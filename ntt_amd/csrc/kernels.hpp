@@ -132,6 +132,8 @@ struct PermTileArgs {
 void launch_permute_tiled(const PermTileArgs &pa, unsigned batch, hipStream_t s);
 
 void launch_crt_reduce(const uint64_t *x, uint32_t *out, size_t n, const CrtPrime &c, hipStream_t s);
+void launch_crt_reduce_all(const uint64_t *a, const uint64_t *b, uint32_t *ra, uint32_t *rb, size_t n,
+                           size_t stride, const CrtConsts &cc, hipStream_t s);
 void launch_crt_merge(const uint32_t *const res[4], uint64_t *out, size_t n, const CrtConsts &cc,
                       hipStream_t s);
 

@@ -216,6 +216,33 @@ __global__ void __launch_bounds__(256) crt_reduce_kernel(const uint64_t *__restr
     out[i] = csub(h + l, c.mp.p);
 }
 
+// Both operands modulo all four primes in one launch (ntt_crt_multiply: a single product is bound by
+// the number of launches): blockIdx.y = operand, out[k] = residues mod m_k at out + k * stride.
+__global__ void __launch_bounds__(256) crt_reduce_all_kernel(const uint64_t *__restrict__ a,
+                                                             const uint64_t *__restrict__ b,
+                                                             uint32_t *__restrict__ ra, uint32_t *__restrict__ rb,
+                                                             size_t n, size_t stride, const CrtConsts cc)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t v = blockIdx.y ? b[i] : a[i];
+    uint32_t *__restrict__ out = blockIdx.y ? rb : ra;
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const CrtPrime &c = cc.prime[k];
+        const uint32_t h = csub(Barrett32::mul_tw(hi, c.two32, c.mp), c.mp.p);
+        out[k * stride + i] = csub(h + red32(lo, c), c.mp.p);
+    }
+}
+
+void launch_crt_reduce_all(const uint64_t *a, const uint64_t *b, uint32_t *ra, uint32_t *rb, size_t n,
+                           size_t stride, const CrtConsts &cc, hipStream_t s)
+{
+    hipLaunchKernelGGL(crt_reduce_all_kernel, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, s, a, b, ra, rb,
+                       n, stride, cc);
+}
+
 void launch_crt_reduce(const uint64_t *x, uint32_t *out, size_t n, const CrtPrime &c, hipStream_t s)
 {
     hipLaunchKernelGGL(crt_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out, n, c);
