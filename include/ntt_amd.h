@@ -185,8 +185,11 @@ int ntt_dist_local_length(const ntt_dist_plan *plan);
 /* Per-kernel timing (HIP events on the context's stream) for bench.py's roofline block.
  * With timing enabled every kernel launch is bracketed by events; ntt_ctx_kernel_time returns
  * the accumulated milliseconds and launch count of kernel `index` (0 .. count-1) and its name;
- * returns NTT_ERR_INVALID past the end.  Reset with ntt_ctx_enable_kernel_timing(ctx, 1). */
+ * returns NTT_ERR_INVALID past the end.  Reset with ntt_ctx_enable_kernel_timing(ctx, 1).
+ * ntt_ctx_kernel_timing_select(ctx, index) restricts the events to kernel `index` (-1: all again), so
+ * that a timed region pays for the events of the kernel it reports only. */
 int ntt_ctx_enable_kernel_timing(ntt_ctx *ctx, int enable);
+int ntt_ctx_kernel_timing_select(ntt_ctx *ctx, int index);
 int ntt_ctx_kernel_time(ntt_ctx *ctx, int index, const char **name, double *total_ms, long *launches);
 
 /* Thread-local message of the last failure in this thread ("" if none). */

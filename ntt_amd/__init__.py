@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = (
     "ntt_plan64_create", "ntt_plan64_destroy", "ntt_plan64_length", "ntt_poly_multiply64_batched",
     "ntt_crt_residue_multiply", "ntt_crt_merge", "ntt_dist_plan_create", "ntt_dist_plan_destroy",
     "ntt_dist_colpass", "ntt_dist_local", "ntt_dist_local_length",
-    "ntt_ctx_enable_kernel_timing", "ntt_ctx_kernel_time", "ntt_last_error", "ntt_read_case",
+    "ntt_ctx_enable_kernel_timing", "ntt_ctx_kernel_timing_select", "ntt_ctx_kernel_time", "ntt_last_error", "ntt_read_case",
     "ntt_check_case", "ntt_write_case", "ntt_poly_multiply_stream", "ntt_host_alloc", "ntt_host_free",
     "ntt_pack_case", "ntt_read_case_bin", "ntt_check_case_bin", "ntt_write_case_bin",
 )
@@ -90,6 +90,7 @@ def _load():
     lib.ntt_dist_local.argtypes = [vp, vp, i32]
     lib.ntt_dist_local_length.argtypes = [vp]
     lib.ntt_ctx_enable_kernel_timing.argtypes = [vp, i32]
+    lib.ntt_ctx_kernel_timing_select.argtypes = [vp, i32]
     lib.ntt_ctx_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                         C.POINTER(C.c_long)]
     lib.ntt_last_error.restype = C.c_char_p
@@ -193,6 +194,21 @@ class Context:
 
     def enable_kernel_timing(self, enable=True):
         _check(_lib.ntt_ctx_enable_kernel_timing(self._h, 1 if enable else 0))
+
+    def kernel_timing_select(self, name=None):
+        """Bracket only the kernel called `name` with events (None: every kernel again)."""
+        index = -1
+        if name is not None:
+            i = 0
+            while True:
+                nm = C.c_char_p()
+                if _lib.ntt_ctx_kernel_time(self._h, i, C.byref(nm), None, None) != OK:
+                    raise ValueError(f"no kernel named {name}")
+                if nm.value.decode() == name:
+                    index = i
+                    break
+                i += 1
+        _check(_lib.ntt_ctx_kernel_timing_select(self._h, index))
 
     def kernel_times(self):
         """{kernel name: (total ms, launches)} accumulated since timing was (re-)enabled."""

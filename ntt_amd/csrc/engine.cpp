@@ -556,15 +556,17 @@ hipEvent_t ntt_ctx::grab_event()
 }
 void ntt_ctx::begin(int id)
 {
-    if (!timing) return;
+    stamp_open = timing && (timing_only < 0 || timing_only == id);
+    if (!stamp_open) return;
     Stamp s{id, grab_event(), grab_event()};
     (void)hipEventRecord(s.e0, cur ? cur : stream);
     stamps.push_back(s);
 }
 void ntt_ctx::end()
 {
-    if (!timing) return;
+    if (!stamp_open) return;
     (void)hipEventRecord(stamps.back().e1, cur ? cur : stream);
+    stamp_open = false;
 }
 int ntt_ctx::fold()
 {
@@ -650,6 +652,15 @@ int ntt_ctx_enable_kernel_timing(ntt_ctx *ctx, int enable)
     int rc = ctx->fold();
     ctx->timing = enable != 0;
     for (int i = 0; i < K_COUNT; ++i) { ctx->acc_ms[i] = 0; ctx->acc_n[i] = 0; }
+    return rc;
+}
+
+int ntt_ctx_kernel_timing_select(ntt_ctx *ctx, int index)
+{
+    if (!ctx || index < -1 || index >= K_COUNT) return fail(NTT_ERR_INVALID, "ntt_ctx_kernel_timing_select: bad index");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ctx->fold();
+    ctx->timing_only = index;
     return rc;
 }
 

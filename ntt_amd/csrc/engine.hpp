@@ -66,6 +66,8 @@ struct ntt_ctx {
 
     // per-kernel timing (bench.py roofline block)
     bool timing = false;
+    int timing_only = -1;                             // >= 0: bracket only this kernel id
+    bool stamp_open = false;                          // begin() recorded a start event
     struct Stamp { int id; hipEvent_t e0, e1; };
     std::vector<Stamp> stamps;
     std::vector<hipEvent_t> event_pool;
