@@ -154,7 +154,10 @@ static int build_tables(ntt_plan *pl)
         }
         int rc = upload_table<MM>(pl, w, &pl->small_w);
         if (rc) return rc;
-        return upload_table<MM>(pl, iw, &pl->small_iw);
+        rc = upload_table<MM>(pl, iw, &pl->small_iw);
+        if (rc || pl->logL < kRowLog) return rc;
+        // L = 4096: products go through the row kernel (row_product_kernel), which needs the roots
+        // and row tables below; ntt_forward / ntt_inverse keep the small kernel
     }
 
     // roots of the 64-point register transform
@@ -364,6 +367,22 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
     const bool neg = pl->negacyclic;
     const uint32_t n = (uint32_t)pl->n, L = pl->L, out_len = neg ? n : 2 * n - 1;
     pl->ctx->cur = pl->ctx->stream;
+    if (pl->logL == kRowLog && pl->twA) {
+        Row4096Args<MM> ra{};
+        ra.row = fill_row<MM>(pl, a, b, ab);
+        ra.in_stride = n; ra.out_stride = ab_stride;
+        ra.in_len = n; ra.out_len = out_len;
+        std::memcpy(&ra.scale, pl->scale_mul.data(), sizeof(ra.scale));
+        if (neg) {
+            ra.twist = static_cast<const typename MM::tw_t *>(pl->twist_fwd);
+            ra.itwist = static_cast<const typename MM::tw_t *>(pl->small_itwist);
+        }
+        ntt_ctx *cx = pl->ctx;
+        cx->begin(K_ROW_MUL);
+        launch_row_product(pl->kind, pl->lazy, &ra, pl->mp, (unsigned)batch, cx->cur);
+        cx->end();
+        return NTT_OK;
+    }
     if (pl->logL <= kRowLog) {
         small_pass<MM>(pl, 0, a, b, ab, n, ab_stride, n, out_len, (unsigned)batch);
         return NTT_OK;

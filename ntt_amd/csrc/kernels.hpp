@@ -48,6 +48,17 @@ struct RowArgs {
     Roots64<MM> roots, iroots;
 };
 
+// A whole product of transform length L = 4096 in the row kernel (no column level): zero padding
+// (loads at or beyond in_len read 0), optional negacyclic twist, scale and output cut included.
+template <class MM>
+struct Row4096Args {
+    RowArgs<MM> row;                     // tables and roots; row.a / row.b / row.out = batch bases
+    size_t in_stride, out_stride;
+    uint32_t in_len, out_len;
+    typename MM::tw_t scale;             // L^-1 (times R for Montgomery's pointwise product)
+    const typename MM::tw_t *twist, *itwist;     // negacyclic: psi^i, and psi^-i with `scale` folded in
+};
+
 // One launch of the software-pipelined fused kernel (kernels_pipe.hip): forward columns of
 // chunk t, row multiply of chunk t-1, inverse columns of chunk t-2.  groups_* = number of column
 // tiles / rows each role owns in this launch (0 = role idle while the pipeline fills or drains).
@@ -94,6 +105,8 @@ void launch_col16(int kind, bool lazy, int logN1, bool inverse, bool half_in, co
 void launch_pipe(int kind, bool lazy, int logN1, const void *args, const ModParams &mp, unsigned groups,
                  hipStream_t s);
 void launch_row_mul(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);
+// L = 4096 exactly: the whole product of one pair in the row kernel (args: Row4096Args<MM>)
+void launch_row_product(int kind, bool lazy, const void *args, const ModParams &mp, unsigned batch, hipStream_t s);
 void launch_row_fwd(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);
 void launch_row_inv(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);
 void launch_small(int kind, bool lazy, const void *args, const ModParams &mp, unsigned batch, hipStream_t s);
