@@ -28,9 +28,23 @@ struct M64 {
     // x * w for any u64 x, wR = w * 2^64 mod p (< p): result in [0, 2p)
     static __device__ __forceinline__ uint64_t mulw(uint64_t x, uint64_t wR, const ModParams64 &m)
     {
-        const uint64_t lo = x * wR, hi = __umul64hi(x, wR);
-        const uint64_t q = lo * m.nprime;
-        return hi + __umul64hi(q, m.p) + (lo != 0 ? 1u : 0u);
+        // 128-bit product from four 32x32->64 multiply-adds (x * wR and __umul64hi(x, wR) written
+        // separately cost seven), q from three, the high half of q * p from four
+        const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32), wl = (uint32_t)wR, wh = (uint32_t)(wR >> 32);
+        const uint64_t t0 = (uint64_t)xl * wl;
+        const uint64_t t1 = (uint64_t)xl * wh + (t0 >> 32);
+        const uint64_t t2 = (uint64_t)xh * wl + (uint32_t)t1;
+        const uint64_t hi = (uint64_t)xh * wh + (t1 >> 32) + (t2 >> 32);
+        const uint32_t lo0 = (uint32_t)t0, lo1 = (uint32_t)t2;
+        const uint32_t nl = (uint32_t)m.nprime, nh = (uint32_t)(m.nprime >> 32);
+        const uint64_t q0 = (uint64_t)lo0 * nl;
+        const uint32_t ql = (uint32_t)q0, qh = (uint32_t)(q0 >> 32) + lo0 * nh + lo1 * nl;
+        const uint32_t pl = (uint32_t)m.p, ph = (uint32_t)(m.p >> 32);
+        const uint64_t u0 = (uint64_t)ql * pl;
+        const uint64_t u1 = (uint64_t)ql * ph + (u0 >> 32);
+        const uint64_t u2 = (uint64_t)qh * pl + (uint32_t)u1;
+        const uint64_t h2 = (uint64_t)qh * ph + (u1 >> 32) + (u2 >> 32);
+        return hi + h2 + ((lo0 | lo1) != 0 ? 1u : 0u);
     }
     static __device__ __forceinline__ uint64_t add(uint64_t u, uint64_t v, const ModParams64 &m)
     {
