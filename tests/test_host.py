@@ -211,3 +211,27 @@ int main() {
         assert v[1] % p == x * w % p and v[1] < 2 * p
         assert v[2] == (p - 1) * (p - 2) % p
     assert lines[2 * len(ps)].split() == ["0", "0", "1"]
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/ntt_amd.h is the boundary a cgo / JNI / ctypes binding consumes: it must compile as C99 (and as
+    C++) on its own, and a C program must link against the library with nothing but the header."""
+    hdr = os.path.join(ROOT, "include", "ntt_amd.h")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr], check=True)
+    src = tmp_path / "probe.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "ntt_amd.h"\n'
+        'int main(void) {\n'
+        '    uint32_t p = 0;\n'
+        '    if (ntt_crt_prime(3, &p) != NTT_OK || p != 998244353u) return 1;\n'
+        '    if (ntt_crt_prime(4, &p) != NTT_ERR_INVALID) return 2;          /* status codes, not exceptions */\n'
+        '    if (ntt_last_error()[0] == 0) return 3;\n'
+        '    printf("ok\\n");\n'
+        '    return 0;\n}\n')
+    exe = tmp_path / "probe"
+    libdir = os.path.join(ROOT, "ntt_amd")
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-L", libdir, "-lntt_amd",
+                    "-Wl,-rpath," + libdir, "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stderr)
