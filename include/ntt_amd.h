@@ -130,6 +130,11 @@ int ntt_inverse(ntt_plan *plan, uint32_t *data, int batch);
  * crt_precompute :449-466, CRT_combine_parallel :468-485 (twins main.cc:813-951). */
 int ntt_crt_multiply(ntt_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *ab, int n,
                      uint64_t p64);
+/* The same for `batch` products at once: a, b are [batch][n], ab is [batch][2n-1] (contiguous rows).
+ * One reduce launch, four batched residue products, one merge launch (the epoch loop of
+ * main-openmp.cc:645-725 runs the branch above once per call; a batch amortises its launches). */
+int ntt_crt_multiply_batched(ntt_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *ab, int n,
+                             uint64_t p64, int batch);
 
 /* Direct 64-bit path: products modulo ONE NTT-friendly prime p64 < 2^62 ((p64 - 1) divisible by
  * L = 2^ceil(log2 2n)) with 64-bit Montgomery lanes (R = 2^64): a, b are [batch][n] u64 with values

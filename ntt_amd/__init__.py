@@ -36,7 +36,7 @@ MONTGOMERY, BARRETT = 0, 1
 EXPORTED_SYMBOLS = (
     "poly_multiply", "ntt_ctx_create", "ntt_ctx_destroy", "ntt_ctx_set_stream", "ntt_ctx_stream",
     "ntt_ctx_synchronize", "ntt_plan_create", "ntt_plan_destroy", "ntt_plan_length",
-    "ntt_poly_multiply_batched", "ntt_forward", "ntt_inverse", "ntt_crt_multiply", "ntt_crt_prime",
+    "ntt_poly_multiply_batched", "ntt_forward", "ntt_inverse", "ntt_crt_multiply", "ntt_crt_multiply_batched", "ntt_crt_prime",
     "ntt_negacyclic_plan_create", "ntt_negacyclic_multiply_batched",
     "ntt_plan64_create", "ntt_plan64_destroy", "ntt_plan64_length", "ntt_poly_multiply64_batched",
     "ntt_crt_residue_multiply", "ntt_crt_merge", "ntt_dist_plan_create", "ntt_dist_plan_destroy",
@@ -75,6 +75,7 @@ def _load():
     lib.ntt_forward.argtypes = [vp, vp, i32]
     lib.ntt_inverse.argtypes = [vp, vp, i32]
     lib.ntt_crt_multiply.argtypes = [vp, vp, vp, vp, i32, u64]
+    lib.ntt_crt_multiply_batched.argtypes = [vp, vp, vp, vp, i32, u64, i32]
     lib.ntt_crt_prime.argtypes = [i32, C.POINTER(u32)]
     lib.ntt_negacyclic_plan_create.argtypes = [vp, u32, i32, i32, i32, C.POINTER(vp)]
     lib.ntt_negacyclic_multiply_batched.argtypes = [vp, vp, vp, vp, sz, i32]
@@ -171,6 +172,15 @@ class Context:
             out = np.zeros(2 * n - 1, dtype=np.uint64)
         _check(_lib.ntt_crt_multiply(self._h, _ptr(a, np.uint64), _ptr(b, np.uint64),
                                      _ptr(out, np.uint64), n, int(p64)))
+        return out
+
+    def crt_multiply_batched(self, a, b, p64, out=None):
+        """[batch, n] uint64 pairs -> [batch, 2n-1] uint64 (``ntt_crt_multiply_batched``)."""
+        batch, n = int(a.shape[0]), int(a.shape[1])
+        if out is None:
+            out = np.zeros((batch, 2 * n - 1), dtype=np.uint64)
+        _check(_lib.ntt_crt_multiply_batched(self._h, _ptr(a, np.uint64), _ptr(b, np.uint64),
+                                             _ptr(out, np.uint64), n, int(p64), batch))
         return out
 
     def crt_residue_multiply(self, a, b, prime_index, out=None):

@@ -34,6 +34,7 @@ void crt_release(ntt_ctx *ctx)
     w.ra.release(); w.rb.release(); w.res.release();
     w.a64.release(); w.b64.release(); w.out64.release(); w.merge_in.release();
     w.n = 0;
+    w.batch = 0;
 }
 
 static int make_consts(uint64_t p64, CrtConsts &cc)
@@ -63,11 +64,21 @@ static int make_consts(uint64_t p64, CrtConsts &cc)
 
 using namespace ntt;
 
+static int crt_plans(ntt_ctx *ctx, int n, int batch);
+
 extern "C" int ntt_crt_multiply(ntt_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *ab, int n,
                                 uint64_t p64)
 {
+    return ntt_crt_multiply_batched(ctx, a, b, ab, n, p64, 1);
+}
+
+// batch products: a, b [batch][n], ab [batch][2n-1] (contiguous rows); batch == 1 is ntt_crt_multiply
+extern "C" int ntt_crt_multiply_batched(ntt_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *ab, int n,
+                                        uint64_t p64, int batch)
+{
     if (!ctx || !a || !b || !ab) return fail(NTT_ERR_INVALID, "ntt_crt_multiply: null argument");
-    if (n <= 0) return fail(NTT_ERR_INVALID, "ntt_crt_multiply: n must be positive");
+    if (n <= 0 || batch <= 0) return fail(NTT_ERR_INVALID, "ntt_crt_multiply: n and batch must be positive");
+    if ((uint64_t)batch * (uint64_t)n > (1ull << 28)) return fail(NTT_ERR_UNSUPPORTED, "ntt_crt_multiply_batched: batch * n above 2^28");
     if ((p64 & 1) == 0 || p64 < 3 || p64 >= (1ULL << 62))
         return fail(NTT_ERR_UNSUPPORTED, "ntt_crt_multiply: p64 must be odd and below 2^62");
     // exactness: every true coefficient < n * (p64-1)^2 must be below M = prod(m_k) (~2^119.6)
@@ -82,16 +93,9 @@ extern "C" int ntt_crt_multiply(ntt_ctx *ctx, const uint64_t *a, const uint64_t 
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     CrtWorkspace &w = ctx->crt;
-    const size_t N = (size_t)n, out_len = 2 * N - 1;
-    if (w.n != n) {
-        crt_release(ctx);
-        for (int k = 0; k < 4; ++k) {
-            int rc = ntt_plan_create(ctx, kCrtMods[k], n, 1, NTT_MODMUL_MONTGOMERY, &w.plans[k]);
-            if (rc) { crt_release(ctx); return rc; }
-        }
-        w.n = n;
-    }
-    int rc = w.ra.ensure(4 * N * 4);
+    const size_t B = (size_t)batch, N = B * (size_t)n, row_len = 2 * (size_t)n - 1, out_len = B * row_len;
+    int rc = crt_plans(ctx, n, batch);
+    if (!rc) rc = w.ra.ensure(4 * N * 4);
     if (!rc) rc = w.rb.ensure(4 * N * 4);
     if (!rc) rc = w.res.ensure(4 * out_len * 4);
     if (rc) return rc;
@@ -124,14 +128,14 @@ extern "C" int ntt_crt_multiply(ntt_ctx *ctx, const uint64_t *a, const uint64_t 
     // main-openmp.cc:697, or MPI rank): primes 1 and 3 run on the context's second lane beside primes 0
     // and 2 -- the kernels of a single product are too small to fill the chip, so the two chains overlap.
     hipStream_t main_stream = ctx->stream;
-    const bool two = ctx->nlanes > 1 && ctx->lane[1] && ctx->lane_limit != 1;
+    const bool two = batch == 1 && ctx->nlanes > 1 && ctx->lane[1] && ctx->lane_limit != 1;   // a batch forks lanes itself
     if (two) {
         HIP_TRY(hipEventRecord(ctx->fork_ev, main_stream));
         HIP_TRY(hipStreamWaitEvent(ctx->lane[1], ctx->fork_ev, 0));
     }
     for (int k = 0; k < 4 && !rc; ++k) {
         ctx->stream = (two && (k & 1)) ? ctx->lane[1] : main_stream;     // the plan's launches follow ctx->stream
-        rc = multiply_device_any(w.plans[k], ra + k * N, rb + k * N, res + k * out_len, out_len, 1);
+        rc = multiply_device_any(w.plans[k], ra + k * N, rb + k * N, res + k * out_len, row_len, batch);
         rows[k] = res + k * out_len;
     }
     ctx->stream = main_stream;
@@ -165,16 +169,17 @@ static int crt_check(ntt_ctx *ctx, int n, uint64_t p64, bool need_p64)
     return NTT_OK;
 }
 
-static int crt_plans(ntt_ctx *ctx, int n)
+static int crt_plans(ntt_ctx *ctx, int n, int batch)
 {
     CrtWorkspace &w = ctx->crt;
-    if (w.n == n) return NTT_OK;
+    if (w.n == n && w.batch >= batch) return NTT_OK;
     crt_release(ctx);
     for (int k = 0; k < 4; ++k) {
-        int rc = ntt_plan_create(ctx, kCrtMods[k], n, 1, NTT_MODMUL_MONTGOMERY, &w.plans[k]);
+        int rc = ntt_plan_create(ctx, kCrtMods[k], n, batch, NTT_MODMUL_MONTGOMERY, &w.plans[k]);
         if (rc) { crt_release(ctx); return rc; }
     }
     w.n = n;
+    w.batch = batch;
     return NTT_OK;
 }
 
@@ -194,7 +199,7 @@ extern "C" int ntt_crt_residue_multiply(ntt_ctx *ctx, const uint64_t *a, const u
         return fail(NTT_ERR_INVALID, "ntt_crt_residue_multiply: bad argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
-    if ((rc = crt_plans(ctx, n))) return rc;
+    if ((rc = crt_plans(ctx, n, 1))) return rc;
     CrtWorkspace &w = ctx->crt;
     const size_t N = (size_t)n, out_len = 2 * N - 1;
     if ((rc = w.ra.ensure(4 * N * 4)) || (rc = w.rb.ensure(4 * N * 4)) || (rc = w.res.ensure(4 * out_len * 4))) return rc;

@@ -32,7 +32,7 @@ struct DeviceBuffer {
 
 // Buffers and per-prime plans of ntt_crt_multiply, cached per context for the last n used.
 struct CrtWorkspace {
-    int n = 0;
+    int n = 0, batch = 0;                 // plans hold `batch` products of length n
     ntt_plan *plans[4] = {nullptr, nullptr, nullptr, nullptr};
     DeviceBuffer ra, rb, res, a64, b64, out64, merge_in;
 };

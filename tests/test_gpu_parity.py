@@ -427,6 +427,32 @@ def test_crt_vs_oracle_large(ctx):
     assert np.array_equal(ctx.crt_multiply(a, b, p64), want)
 
 
+def test_crt_batched(ctx, crt_vectors):
+    """ntt_crt_multiply_batched: host and device arrays, every row against the single-product call and the
+    oracle; switching between batch sizes and back to single products reuses / rebuilds the cached plans."""
+    import torch
+    p64 = 1337006139375617
+    rng = np.random.default_rng(12)
+    n, B = 3000, 7
+    a = rng.integers(0, p64, size=(B, n), dtype=np.uint64)
+    b = rng.integers(0, p64, size=(B, n), dtype=np.uint64)
+    got = ctx.crt_multiply_batched(a, b, p64)
+    for i in range(B):
+        want, _ = orc.poly_multiply_crt(a[i], b[i], p64, threads=4)
+        assert np.array_equal(got[i], want), i
+    assert np.array_equal(ctx.crt_multiply(a[2], b[2], p64), got[2])               # back to one product
+    da = torch.from_numpy(a.view(np.int64)).cuda()
+    db = torch.from_numpy(b.view(np.int64)).cuda()
+    out = torch.zeros((B, 2 * n - 1), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.crt_multiply_batched(da[:3].contiguous(), db[:3].contiguous(), p64, out=out[:3])     # smaller batch, cached plans
+    ctx.synchronize()
+    assert np.array_equal(out[:3].cpu().numpy().view(np.uint64), got[:3])
+    v = crt_vectors                                                                  # golden big-integer vectors
+    g = ctx.crt_multiply_batched(np.stack([v["a_256"], v["a_256"]]), np.stack([v["b_256"], v["b_256"]]), int(v["p64"]))
+    assert np.array_equal(g[0], v["ab_256"]) and np.array_equal(g[1], v["ab_256"])
+
+
 def test_crt_sharded_world1(nt, ctx):
     """The prime-per-GPU CRT driver (ntt_amd.shard.crt_multiply_sharded) fed by the real C-ABI halves
     ntt_crt_residue_multiply / ntt_crt_merge, world_size 1 (the exchange itself is covered by the gloo

@@ -105,6 +105,23 @@ def main():
                       "cpu_oracle_ms_per_product": cpu_s * 1e3,
                       "reference_published_ms": 90.7393}), flush=True)
 
+    B3 = 64
+    ya = torch.from_numpy((orc.splitmix64_np(5, B3 * n) % np.uint64(p64)).view(np.int64).reshape(B3, n)).cuda()
+    yb = torch.from_numpy((orc.splitmix64_np(6, B3 * n) % np.uint64(p64)).view(np.int64).reshape(B3, n)).cuda()
+    yo = torch.zeros((B3, 2 * n - 1), dtype=torch.int64, device="cuda")
+    ctx.crt_multiply_batched(ya, yb, p64, out=yo)
+    sync()
+    assert np.array_equal(yo[0].cpu().numpy().view(np.uint64),
+                          orc.poly_multiply_crt(ya[0].cpu().numpy().view(np.uint64), yb[0].cpu().numpy().view(np.uint64), p64, threads=8)[0])
+    t0 = time.perf_counter()
+    for _ in range(10):
+        ctx.crt_multiply_batched(ya, yb, p64, out=yo)
+    sync()
+    dtb3 = (time.perf_counter() - t0) / 10 / B3
+    print(json.dumps({"config": "3 batched: 64 CRT products per call (ntt_crt_multiply_batched)",
+                      "ms_per_product": dtb3 * 1e3, "products_per_s": 1 / dtb3}), flush=True)
+    del ya, yb, yo
+
     # ---- config 3 through the direct 64-bit path (one 64-bit transform per operand instead of four primes)
     plan64 = ctx.plan64(p64, n, batch=64)
     plan64.multiply(da, db, out=dab, batch=1)
