@@ -776,6 +776,10 @@ static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_ki
     pl->lazy = p < (1u << 30);
     if (const char *e = std::getenv("NTT_AMD_FORCE_STRICT"))
         if (e[0] == '1') pl->lazy = false;
+    // forward column pass: the register kernel wins in a full launch, the LDS-staged one (four times the
+    // workgroups, a quarter of the work per thread) when a launch holds a few products only
+    // (single product: 9.7 -> 8.2 us, tools/time_single.py)
+    pl->col16_fwd = batch <= 4;
     if (const char *e = std::getenv("NTT_AMD_COL16")) {
         const int v = std::atoi(e);
         pl->col16_fwd = v & 1;
