@@ -149,6 +149,12 @@ int ntt_plan64_destroy(ntt_plan64 *plan);
 int ntt_plan64_length(const ntt_plan64 *plan, uint32_t *L);
 int ntt_poly_multiply64_batched(ntt_plan64 *plan, const uint64_t *a, const uint64_t *b, uint64_t *ab,
                                 size_t ab_stride, int batch);
+/* Negacyclic products with 64-bit lanes: c = a * b mod (x^n + 1, p64), n a power of two, 2n | p64 - 1;
+ * c is [batch][n] with row stride c_stride.  The 64-bit twin of ntt_negacyclic_* below (FHE-style RNS
+ * limbs are usually 50-60-bit primes). */
+int ntt_negacyclic_plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, ntt_plan64 **out);
+int ntt_negacyclic_multiply64_batched(ntt_plan64 *plan, const uint64_t *a, const uint64_t *b, uint64_t *c,
+                                      size_t c_stride, int batch);
 
 /* The two halves of ntt_crt_multiply as separate calls, for the prime-per-GPU sharding of the
  * reference's MPI driver (main-mpi.cc:657-660 gives each rank ceil(4/size) primes, :770 runs

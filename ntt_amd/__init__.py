@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = (
     "ntt_ctx_synchronize", "ntt_plan_create", "ntt_plan_destroy", "ntt_plan_length",
     "ntt_poly_multiply_batched", "ntt_forward", "ntt_inverse", "ntt_crt_multiply", "ntt_crt_multiply_batched", "ntt_crt_prime",
     "ntt_negacyclic_plan_create", "ntt_negacyclic_multiply_batched",
+    "ntt_negacyclic_plan64_create", "ntt_negacyclic_multiply64_batched",
     "ntt_plan64_create", "ntt_plan64_destroy", "ntt_plan64_length", "ntt_poly_multiply64_batched",
     "ntt_crt_residue_multiply", "ntt_crt_merge", "ntt_dist_plan_create", "ntt_dist_plan_destroy",
     "ntt_dist_colpass", "ntt_dist_local", "ntt_dist_local_length",
@@ -80,6 +81,8 @@ def _load():
     lib.ntt_negacyclic_plan_create.argtypes = [vp, u32, i32, i32, i32, C.POINTER(vp)]
     lib.ntt_negacyclic_multiply_batched.argtypes = [vp, vp, vp, vp, sz, i32]
     lib.ntt_plan64_create.argtypes = [vp, u64, i32, i32, C.POINTER(vp)]
+    lib.ntt_negacyclic_plan64_create.argtypes = [vp, u64, i32, i32, C.POINTER(vp)]
+    lib.ntt_negacyclic_multiply64_batched.argtypes = [vp, vp, vp, vp, sz, i32]
     lib.ntt_plan64_destroy.argtypes = [vp]
     lib.ntt_plan64_length.argtypes = [vp, C.POINTER(u32)]
     lib.ntt_poly_multiply64_batched.argtypes = [vp, vp, vp, vp, sz, i32]
@@ -164,6 +167,9 @@ class Context:
 
     def plan64(self, p64, n, batch=1):
         return Plan64(self, p64, n, batch)
+
+    def negacyclic_plan64(self, p64, n, batch=1):
+        return Plan64(self, p64, n, batch, negacyclic=True)
 
     def crt_multiply(self, a, b, p64, out=None):
         """Large-modulus product (main-openmp.cc:693-711): a, b uint64 < p64; returns 2n-1 uint64."""
@@ -314,11 +320,12 @@ class NegacyclicPlan(Plan):
 class Plan64:
     """Products modulo one NTT-friendly prime below 2^62 with 64-bit lanes (``ntt_plan64``)."""
 
-    def __init__(self, ctx, p64, n, batch=1):
+    def __init__(self, ctx, p64, n, batch=1, negacyclic=False):
         h = C.c_void_p()
-        _check(_lib.ntt_plan64_create(ctx._h, int(p64), int(n), int(batch), C.byref(h)))
+        create = _lib.ntt_negacyclic_plan64_create if negacyclic else _lib.ntt_plan64_create
+        _check(create(ctx._h, int(p64), int(n), int(batch), C.byref(h)))
         self._h = h
-        self.ctx, self.p, self.n, self.batch = ctx, int(p64), int(n), int(batch)
+        self.ctx, self.p, self.n, self.batch, self.negacyclic = ctx, int(p64), int(n), int(batch), negacyclic
         L = C.c_uint32()
         _check(_lib.ntt_plan64_length(h, C.byref(L)))
         self.length = L.value
@@ -339,11 +346,11 @@ class Plan64:
         if batch is None:
             batch = int(a.shape[0]) if getattr(a, "ndim", 1) == 2 or (hasattr(a, "dim") and a.dim() == 2) else 1
         if out_stride is None:
-            out_stride = 2 * self.n - 1
+            out_stride = self.n if self.negacyclic else 2 * self.n - 1
         if out is None:
             out = np.zeros((batch, out_stride), dtype=np.uint64)
-        _check(_lib.ntt_poly_multiply64_batched(self._h, _ptr(a, np.uint64), _ptr(b, np.uint64),
-                                                _ptr(out, np.uint64), out_stride, batch))
+        fn = _lib.ntt_negacyclic_multiply64_batched if self.negacyclic else _lib.ntt_poly_multiply64_batched
+        _check(fn(self._h, _ptr(a, np.uint64), _ptr(b, np.uint64), _ptr(out, np.uint64), out_stride, batch))
         return out
 
 

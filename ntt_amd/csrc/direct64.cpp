@@ -37,6 +37,8 @@ struct ntt_plan64 {
     uint64_t *twA = nullptr, *twB = nullptr, *itwA = nullptr, *itwB = nullptr;   // row64_mul_kernel
     Roots16x64 roots{}, iroots{};
     uint64_t scale = 0;                     // L^-1 * R (cancels the pointwise R^-1), Montgomery form
+    bool negacyclic = false;                // products modulo x^n + 1: L = n, psi twist
+    uint64_t *twist_fwd = nullptr, *twist_inv = nullptr, *small_itwist = nullptr;
     DeviceBuffer work0, work1, stage_a, stage_b, stage_out;
     std::vector<void *> owned;
 };
@@ -124,6 +126,16 @@ int build_tables(ntt_plan64 *pl)
     const uint64_t invL = powmod(L % p, p - 2, p);
     const uint64_t scale = mulmod(invL, mp.r1, p);                  // L^-1 * R
     pl->scale = to_mont(scale, mp);
+    if (pl->negacyclic) {      // psi = g^((p-1)/2L), psi^2 = wL; row 1 of a 2-row power table is psi^i
+        const uint64_t psi = powmod(pl->g, (p - 1) / (2ull * L), p), ipsi = powmod(psi, p - 2, p);
+        int rc = upload(pl, power_table(psi, 2, L, 1, mp), &pl->twist_fwd);
+        if (!rc) rc = upload(pl, power_table(ipsi, 2, L, 1, mp), &pl->twist_inv);
+        if (!rc) rc = upload(pl, power_table(ipsi, 2, L, scale, mp), &pl->small_itwist);
+        if (rc) return rc;
+        pl->twist_fwd += L;
+        pl->twist_inv += L;
+        pl->small_itwist += L;
+    }
     const int rowlog = std::min(pl->logL, kRowLog);
     const uint32_t len = 1u << rowlog;
     // row tables: w_len^j, j < len/2
@@ -185,6 +197,7 @@ Col64Args fill_col(ntt_plan64 *pl, int level, bool inverse, const uint64_t *in0,
     a.scale0 = pl->scale;
     a.canon = canon ? 1 : 0;
     a.roots = inverse ? pl->iroots : pl->roots;
+    a.twist = (pl->negacyclic && level == 0) ? (inverse ? pl->twist_inv : pl->twist_fwd) : nullptr;
     return a;
 }
 
@@ -192,7 +205,8 @@ Col64Args fill_col(ntt_plan64 *pl, int level, bool inverse, const uint64_t *in0,
 int multiply_device(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64_t *ab, size_t ab_stride, int batch)
 {
     ntt_ctx *cx = pl->ctx;
-    const uint32_t n = (uint32_t)pl->n, L = pl->L, out_len = 2 * n - 1;
+    const bool neg = pl->negacyclic;
+    const uint32_t n = (uint32_t)pl->n, L = pl->L, out_len = neg ? n : 2 * n - 1;
     hipStream_t s = cx->stream;
     cx->cur = s;
     if (pl->nlevels == 0) {
@@ -203,6 +217,7 @@ int multiply_device(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64
         r.blocks_per_row = 1; r.logLen = pl->logL;
         r.w = pl->row_w; r.iw = pl->row_iw;
         r.scale = pl->scale; r.use_scale = 1; r.canon = 1; r.mode = 0;
+        if (neg) { r.twist = pl->twist_fwd; r.itwist = pl->small_itwist; }
         cx->begin(K_LDS64);
         launch_lds64(r, pl->mp, (unsigned)batch, s);
         cx->end();
@@ -219,7 +234,7 @@ int multiply_device(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64
         const Col64Args ca = j == 0 ? fill_col(pl, 0, false, a, b, w0, w1, n, L, n, L, false)
                                     : fill_col(pl, j, false, w0, w1, w0, w1, L, L, L, L, false);
         cx->begin(K_COL64);
-        launch_col64(pl->level_log[j], false, j == 0, ca, pl->mp, L >> pl->level_log[j], (unsigned)batch, 2, s);
+        launch_col64(pl->level_log[j], false, j == 0 && !neg, ca, pl->mp, L >> pl->level_log[j], (unsigned)batch, 2, s);
         cx->end();
     }
     // rows: forward a, forward b, pointwise, inverse
@@ -246,7 +261,20 @@ int multiply_device(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64
 
 }  // namespace
 
+static int plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, bool negacyclic, ntt_plan64 **out);
+
 extern "C" int ntt_plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, ntt_plan64 **out)
+{
+    return plan64_create(ctx, p64, n, batch, false, out);
+}
+
+extern "C" int ntt_negacyclic_plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, ntt_plan64 **out)
+{
+    if (n < 2 || (n & (n - 1)) != 0) return fail(NTT_ERR_INVALID, "ntt_negacyclic_plan64_create: n must be a power of two >= 2");
+    return plan64_create(ctx, p64, n, batch, true, out);
+}
+
+static int plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, bool negacyclic, ntt_plan64 **out)
 {
     if (!ctx || !out) return fail(NTT_ERR_INVALID, "ntt_plan64_create: null argument");
     if (n <= 0 || batch <= 0) return fail(NTT_ERR_INVALID, "ntt_plan64_create: n and batch must be positive");
@@ -255,7 +283,8 @@ extern "C" int ntt_plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, n
         return fail(NTT_ERR_UNSUPPORTED, "ntt_plan64_create: p64 must be a prime below 2^62");
     int lg = 1;
     while ((1ull << lg) < 2ull * (uint64_t)n) ++lg;                // smallest power of two >= 2n, at least 2
-    if ((p64 - 1) % (1ull << lg) != 0)
+    if (negacyclic) --lg;                                          // x^n + 1: transform length n, 2n-th root psi
+    if ((p64 - 1) % (1ull << (negacyclic ? lg + 1 : lg)) != 0)
         return fail(NTT_ERR_UNSUPPORTED, "ntt_plan64_create: p64 - 1 is not divisible by the transform length");
     if ((uint64_t)batch << lg > (1ull << 29))
         return fail(NTT_ERR_UNSUPPORTED, "ntt_plan64_create: batch * L above 2^29 elements");
@@ -266,6 +295,7 @@ extern "C" int ntt_plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, n
     pl->p = p64;
     pl->n = n;
     pl->batch = batch;
+    pl->negacyclic = negacyclic;
     pl->logL = lg;
     pl->L = 1u << lg;
     pl->mp = make_params(p64);
@@ -314,14 +344,31 @@ extern "C" int ntt_plan64_length(const ntt_plan64 *pl, uint32_t *L)
     return NTT_OK;
 }
 
+static int multiply64_entry(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64_t *ab, size_t ab_stride,
+                            int batch, bool negacyclic);
+
 extern "C" int ntt_poly_multiply64_batched(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64_t *ab,
                                            size_t ab_stride, int batch)
 {
+    return multiply64_entry(pl, a, b, ab, ab_stride, batch, false);
+}
+
+extern "C" int ntt_negacyclic_multiply64_batched(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64_t *c,
+                                                 size_t c_stride, int batch)
+{
+    return multiply64_entry(pl, a, b, c, c_stride, batch, true);
+}
+
+static int multiply64_entry(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64_t *ab, size_t ab_stride,
+                            int batch, bool negacyclic)
+{
     if (!pl || !a || !b || !ab) return fail(NTT_ERR_INVALID, "ntt_poly_multiply64_batched: null argument");
+    if (pl->negacyclic != negacyclic)
+        return fail(NTT_ERR_INVALID, "ntt_poly_multiply64_batched / ntt_negacyclic_multiply64_batched: wrong kind of plan");
     if (batch <= 0 || batch > pl->batch)
         return fail(NTT_ERR_INVALID, "ntt_poly_multiply64_batched: batch must be in 1..plan capacity");
-    const size_t n = (size_t)pl->n, out_len = 2 * n - 1;
-    if (ab_stride < out_len) return fail(NTT_ERR_INVALID, "ntt_poly_multiply64_batched: ab_stride < 2n-1");
+    const size_t n = (size_t)pl->n, out_len = negacyclic ? n : 2 * n - 1;
+    if (ab_stride < out_len) return fail(NTT_ERR_INVALID, "ntt_poly_multiply64_batched: output row stride below the row length");
     ntt_ctx *cx = pl->ctx;
     std::lock_guard<std::mutex> lk(cx->mu);
     HIP_TRY(hipSetDevice(cx->device));

@@ -169,6 +169,7 @@ struct Col64Args {
     int use_scale0;
     int canon;
     Roots16x64 roots;
+    const uint64_t *twist;               // negacyclic: [L] psi^(+-i), Montgomery form; nullptr otherwise
 };
 struct Lds64Args {
     const uint64_t *a, *b;
@@ -180,6 +181,7 @@ struct Lds64Args {
     const uint64_t *w, *iw;              // w_len^j, w_len^-j, j < len/2, Montgomery form
     uint64_t scale;
     int use_scale, canon, mode;          // mode 0 multiply, 1 forward, 2 inverse
+    const uint64_t *twist, *itwist;      // negacyclic multiply: psi^i, and psi^-i with the scale folded in
 };
 struct Row64Args {
     const uint64_t *a, *b;               // [rows][4096]

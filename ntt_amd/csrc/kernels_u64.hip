@@ -124,6 +124,11 @@ __global__ void __launch_bounds__(256) col64_kernel(const Col64Args a, const Mod
             x[i1] = idx < a.in_len ? in[idx] : 0ull;
         }
     }
+    if (!INVERSE && a.twist) {                                // negacyclic: x[i] * psi^i (uniform branch)
+#pragma unroll
+        for (int i1 = 0; i1 < N1; ++i1)
+            if (!(HALF && i1 >= N1 / 2)) x[i1] = M64::mulw(x[i1], a.twist[base + ((uint32_t)i1 << a.logS)], m);
+    }
     if constexpr (INVERSE) {
         if (a.use_scale0) x[0] = M64::mulw(x[0], a.scale0, m);
 #pragma unroll
@@ -137,7 +142,9 @@ __global__ void __launch_bounds__(256) col64_kernel(const Col64Args a, const Mod
 #pragma unroll
     for (int k1 = 0; k1 < N1; ++k1) {
         const uint32_t idx = base + ((uint32_t)k1 << a.logS);
-        const uint64_t v = a.canon ? M64::canon(x[k1], m) : x[k1];
+        uint64_t v = x[k1];
+        if (INVERSE && a.canon && a.twist) v = M64::mulw(v, a.twist[idx], m);      // negacyclic: result * psi^-i
+        if (a.canon) v = M64::canon(v, m);
         if (idx < a.out_len) out[idx] = v;
     }
 }
@@ -214,7 +221,12 @@ __global__ void __launch_bounds__(256) lds64_kernel(const Lds64Args a, const Mod
     uint64_t *__restrict__ po = a.out + (size_t)row * a.out_stride + off;
     const uint32_t in_len = a.in_len, out_len = a.out_len;        // per row, relative to `off` = 0 when blocks_per_row == 1
 
-    for (uint32_t i = threadIdx.x; i < len; i += 256) lds[i] = (off + i) < in_len ? pa[i] : 0ull;
+    const bool neg = a.mode == 0 && a.twist != nullptr;       // negacyclic multiply (whole transform in this block)
+    for (uint32_t i = threadIdx.x; i < len; i += 256) {
+        uint64_t v = (off + i) < in_len ? pa[i] : 0ull;
+        if (neg) v = M64::mulw(v, a.twist[i], m);
+        lds[i] = v;
+    }
     __syncthreads();
     if (a.mode == 2) {
         lds_inverse64(lds, a.logLen, a.iw, m);
@@ -229,7 +241,11 @@ __global__ void __launch_bounds__(256) lds64_kernel(const Lds64Args a, const Mod
                 ra[k] = i < len ? lds[i] : 0ull;
             }
             __syncthreads();
-            for (uint32_t i = threadIdx.x; i < len; i += 256) lds[i] = (off + i) < in_len ? pb[i] : 0ull;
+            for (uint32_t i = threadIdx.x; i < len; i += 256) {
+                uint64_t v = (off + i) < in_len ? pb[i] : 0ull;
+                if (neg) v = M64::mulw(v, a.twist[i], m);
+                lds[i] = v;
+            }
             __syncthreads();
             lds_forward64(lds, a.logLen, a.w, m);
 #pragma unroll
@@ -244,7 +260,8 @@ __global__ void __launch_bounds__(256) lds64_kernel(const Lds64Args a, const Mod
     }
     for (uint32_t i = threadIdx.x; i < len; i += 256) {
         uint64_t v = lds[i];
-        if (a.use_scale) v = M64::mulw(v, a.scale, m);
+        if (neg) v = M64::mulw(v, a.itwist[i], m);            // psi^-i with the scale folded in
+        else if (a.use_scale) v = M64::mulw(v, a.scale, m);
         if (a.canon) v = M64::canon(v, m);
         if ((off + i) < out_len) po[i] = v;
     }

@@ -174,3 +174,82 @@ def test_negacyclic_from_reference_golden(nt, ctx, nttdata, cid, kind):
     got = plan.multiply(a.astype(np.uint32), b.astype(np.uint32))[0]
     plan.close()
     assert np.array_equal(got, want)
+
+
+# ---- 64-bit lanes (ntt_negacyclic_plan64_create / ntt_negacyclic_multiply64_batched) ------------------------
+P51 = 1337006139375617            # the reference's large modulus, 2-adicity 46
+P62 = 4611685941117976577         # largest prime k * 2^32 + 1 below 2^62
+
+
+def fold(ab, n, p):
+    """c[i] = ab[i] - ab[i + n] (mod p) of a linear product of two length-n polynomials (Python integers)."""
+    ab = [int(v) for v in ab]
+    return np.array([(ab[i] - (ab[i + n] if i + n < len(ab) else 0)) % p for i in range(n)], dtype=np.uint64)
+
+
+@pytest.mark.parametrize("n", [2, 8, 256, 4096, 8192, 65536, 131072])
+def test_negacyclic64_vs_linear_crt_oracle(ctx, n):
+    """Small block (L <= 4096), one column level, two levels; against the 4-prime CRT oracle's linear product."""
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, P51, size=n, dtype=np.uint64)
+    b = rng.integers(0, P51, size=n, dtype=np.uint64)
+    a[-1] = P51 - 1
+    b[-1] = P51 - 1
+    lin, _ = orc.poly_multiply_crt(a, b, P51, threads=8)
+    plan = ctx.negacyclic_plan64(P51, n)
+    got = plan.multiply(a, b)[0]
+    plan.close()
+    assert np.array_equal(got, fold(lin, n, P51))
+
+
+def test_negacyclic64_golden_and_schoolbook(ctx, crt_vectors):
+    v = crt_vectors                       # big-integer golden linear product, n = 256
+    plan = ctx.negacyclic_plan64(int(v["p64"]), 256)
+    assert np.array_equal(plan.multiply(v["a_256"], v["b_256"])[0], fold(v["ab_256"], 256, int(v["p64"])))
+    plan.close()
+    rng = np.random.default_rng(3)
+    for n in (2, 4, 32):                  # a 62-bit prime: Python schoolbook
+        a = rng.integers(0, P62, size=n, dtype=np.uint64)
+        b = rng.integers(0, P62, size=n, dtype=np.uint64)
+        c = [0] * n
+        for i in range(n):
+            for j in range(n):
+                t = int(a[i]) * int(b[j])
+                if i + j < n:
+                    c[i + j] += t
+                else:
+                    c[i + j - n] -= t
+        plan = ctx.negacyclic_plan64(P62, n)
+        got = plan.multiply(a, b)[0]
+        plan.close()
+        assert np.array_equal(got, np.array([x % P62 for x in c], dtype=np.uint64)), n
+
+
+def test_negacyclic64_ring_identity_and_batch(nt, ctx):
+    """62-bit prime at n = 2^15, a batch on device arrays with a padded row stride: x^k * a rotates with a sign."""
+    import torch
+    n, B, p = 32768, 5, P62
+    rng = np.random.default_rng(4)
+    a = rng.integers(0, p, size=(B, n), dtype=np.uint64)
+    xk = np.zeros((B, n), dtype=np.uint64)
+    ks = [1, 2, 100, n - 1, 0]
+    for i, k in enumerate(ks):
+        xk[i, k] = 1
+    da = torch.from_numpy(a.view(np.int64)).cuda()
+    dx = torch.from_numpy(xk.view(np.int64)).cuda()
+    out = torch.full((B, n + 2), -1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    plan = ctx.negacyclic_plan64(p, n, batch=8)
+    plan.multiply(da, dx, out=out, batch=B, out_stride=n + 2)
+    ctx.synchronize()
+    got = out.cpu().numpy()
+    assert (got[:, n:] == -1).all()
+    for i, k in enumerate(ks):
+        ai = [int(v) for v in a[i]]
+        want = np.array([(p - v) % p for v in ai[n - k:]] + ai[:n - k], dtype=np.uint64) if k else a[i]
+        assert np.array_equal(got[i, :n].view(np.uint64), want), k
+    with pytest.raises(nt.NttError):                       # plan kinds do not mix
+        nt._check(nt._lib.ntt_poly_multiply64_batched(plan._h, da.data_ptr(), dx.data_ptr(), out.data_ptr(), 2 * n, 1))
+    plan.close()
+    with pytest.raises(nt.NttError):
+        ctx.negacyclic_plan64(p, 1000)

@@ -631,6 +631,21 @@ def test_kernel_timing(ctx):
     ctx.enable_kernel_timing(False)
     assert t["col_fwd"][1] == 1 and t["row_mul"][1] == 1 and t["col_inv"][1] == 1
     assert t["row_mul"][0] > 0
+    # events for one kernel only (what bench.py's timed region uses), then for all again
+    ctx.kernel_timing_select("row_mul")
+    ctx.enable_kernel_timing(True)
+    plan.multiply(a, a)
+    plan.multiply(a, a)
+    t = ctx.kernel_times()
+    assert t["row_mul"][1] == 2 and t["col_fwd"][1] == 0 and t["col_inv"][1] == 0
+    ctx.kernel_timing_select(None)
+    ctx.enable_kernel_timing(True)
+    plan.multiply(a, a)
+    t = ctx.kernel_times()
+    ctx.enable_kernel_timing(False)
+    assert t["row_mul"][1] == 1 and t["col_fwd"][1] == 1
+    with pytest.raises(ValueError):
+        ctx.kernel_timing_select("no_such_kernel")
     plan.close()
 
 
