@@ -7,6 +7,7 @@
 // 4-prime CRT (:693-711, here ntt_crt_multiply).  This is the same branch with lanes wide enough
 // for the 51-bit modulus of the reference's fifth test case, so that case can be computed two ways.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -36,6 +37,7 @@ struct ntt_plan64 {
     uint64_t *row_w = nullptr, *row_iw = nullptr;             // lds64_kernel (L <= 4096)
     uint64_t *twA = nullptr, *twB = nullptr, *itwA = nullptr, *itwB = nullptr;   // row64_mul_kernel
     Roots16x64 roots{}, iroots{};
+    std::vector<uint64_t> tw_in_fwd[8], tw_in_inv[8];         // per level of 32 / 64 points: w_N1^(+-r*ka)
     uint64_t scale = 0;                     // L^-1 * R (cancels the pointwise R^-1), Montgomery form
     bool negacyclic = false;                // products modulo x^n + 1: L = n, psi twist
     uint64_t *twist_fwd = nullptr, *twist_inv = nullptr, *small_itwist = nullptr;
@@ -175,6 +177,16 @@ int build_tables(ntt_plan64 *pl)
         const uint32_t M = 1u << pl->level_logM[j], N1 = 1u << pl->level_log[j], S = M / N1;
         const uint64_t wM = powmod(wL, L / M, p), iwM = powmod(iwL, L / M, p);
         const bool innermost = (j == pl->nlevels - 1);
+        if (pl->level_log[j] >= 5) {                     // inner twiddles of the LDS-staged level
+            const uint64_t wN = powmod(wL, L / N1, p), iwN = powmod(iwL, L / N1, p);
+            pl->tw_in_fwd[j].assign(64, 0);
+            pl->tw_in_inv[j].assign(64, 0);
+            for (uint32_t r = 0; r < 4; ++r)
+                for (uint32_t ka = 0; ka < 16; ++ka) {
+                    pl->tw_in_fwd[j][r * 16 + ka] = to_mont(powmod(wN, (uint64_t)r * ka, p), mp);
+                    pl->tw_in_inv[j][r * 16 + ka] = to_mont(powmod(iwN, (uint64_t)r * ka, p), mp);
+                }
+        }
         int rc = upload(pl, power_table(wM, N1, S, 1, mp), &pl->tw_fwd[j]);
         if (rc) return rc;
         if ((rc = upload(pl, power_table(iwM, N1, S, innermost ? scale : 1, mp), &pl->tw_inv[j]))) return rc;
@@ -198,6 +210,10 @@ Col64Args fill_col(ntt_plan64 *pl, int level, bool inverse, const uint64_t *in0,
     a.canon = canon ? 1 : 0;
     a.roots = inverse ? pl->iroots : pl->roots;
     a.twist = (pl->negacyclic && level == 0) ? (inverse ? pl->twist_inv : pl->twist_fwd) : nullptr;
+    if (pl->level_log[level] >= 5) {
+        const auto &src = inverse ? pl->tw_in_inv[level] : pl->tw_in_fwd[level];
+        std::memcpy(a.tw_in, src.data(), sizeof(a.tw_in));
+    }
     return a;
 }
 
@@ -234,7 +250,8 @@ int multiply_device(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64
         const Col64Args ca = j == 0 ? fill_col(pl, 0, false, a, b, w0, w1, n, L, n, L, false)
                                     : fill_col(pl, j, false, w0, w1, w0, w1, L, L, L, L, false);
         cx->begin(K_COL64);
-        launch_col64(pl->level_log[j], false, j == 0 && !neg, ca, pl->mp, L >> pl->level_log[j], (unsigned)batch, 2, s);
+        (pl->level_log[j] >= 5 ? launch_col64x : launch_col64)(pl->level_log[j], false, j == 0 && !neg, ca, pl->mp,
+                                                               L >> pl->level_log[j], (unsigned)batch, 2, s);
         cx->end();
     }
     // rows: forward a, forward b, pointwise, inverse
@@ -252,7 +269,8 @@ int multiply_device(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64
         const Col64Args ca = j == 0 ? fill_col(pl, 0, true, w0, nullptr, ab, nullptr, L, ab_stride, L, out_len, true)
                                     : fill_col(pl, j, true, w0, nullptr, w0, nullptr, L, L, L, L, false);
         cx->begin(K_COL64);
-        launch_col64(pl->level_log[j], true, false, ca, pl->mp, L >> pl->level_log[j], (unsigned)batch, 1, s);
+        (pl->level_log[j] >= 5 ? launch_col64x : launch_col64)(pl->level_log[j], true, false, ca, pl->mp,
+                                                               L >> pl->level_log[j], (unsigned)batch, 1, s);
         cx->end();
     }
     HIP_TRY(hipGetLastError());
@@ -305,14 +323,16 @@ static int plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, bool nega
     while (powmod(g, (p64 - 1) / 2, p64) != p64 - 1) ++g;
     pl->g = g;
     if (lg > kRowLog) {
-        int rest = lg - kRowLog, m = 0, logM = lg;
-        while (rest > 0) {
-            const int l = std::min(rest, 4);
-            pl->level_log[m] = l;
-            pl->level_logM[m] = logM;
-            logM -= l;
-            rest -= l;
-            ++m;
+        // column levels of at most 64 points: 5 or 6 bits go through the LDS-staged kernel (one pass over
+        // memory), up to 4 bits through the register kernel
+        int maxlog = 6;
+        if (const char *e = std::getenv("NTT_AMD_COL64_MAXLOG")) maxlog = std::max(1, std::min(6, std::atoi(e)));
+        const int c = lg - kRowLog, m = (c + maxlog - 1) / maxlog;
+        int logM = lg;
+        for (int j = 0; j < m; ++j) {
+            pl->level_log[j] = c / m + (j < c % m ? 1 : 0);
+            pl->level_logM[j] = logM;
+            logM -= pl->level_log[j];
         }
         pl->nlevels = m;
     }

@@ -170,6 +170,7 @@ struct Col64Args {
     int canon;
     Roots16x64 roots;
     const uint64_t *twist;               // negacyclic: [L] psi^(+-i), Montgomery form; nullptr otherwise
+    uint64_t tw_in[64];                  // LDS-staged levels of 32 / 64 points: w_N1^(+-r*ka), index r*16 + ka
 };
 struct Lds64Args {
     const uint64_t *a, *b;
@@ -193,6 +194,9 @@ struct Row64Args {
 void launch_row64_mul(const Row64Args &a, const ModParams64 &mp, unsigned rows, hipStream_t s);
 void launch_col64(int logN1, bool inverse, bool half_in, const Col64Args &a, const ModParams64 &mp,
                   unsigned cols_per_row, unsigned batch, unsigned nops, hipStream_t s);
+// LDS-staged column level of N1 = 32 or 64 points (logN1 = 5, 6): 16 points per thread, one exchange
+void launch_col64x(int logN1, bool inverse, bool half_in, const Col64Args &a, const ModParams64 &mp,
+                   unsigned cols_per_row, unsigned batch, unsigned nops, hipStream_t s);
 void launch_lds64(const Lds64Args &a, const ModParams64 &mp, unsigned blocks, hipStream_t s);
 
 }  // namespace ntt

@@ -170,6 +170,96 @@ void launch_col64(int logN1, bool inverse, bool half_in, const Col64Args &a, con
     }
 }
 
+// ---- LDS-staged column level: N1 = 16 * R points, R = 2 or 4 -------------------------------------------------
+// Same scheme as the 32-bit col16 kernel (col16_body.hpp): a workgroup owns C = 256/R columns x N1 rows;
+// thread (c, r) transforms rows R*j + r (16 points, registers), multiplies by the inner twiddle
+// w_N1^(r*ka), the 32 KiB tile goes through LDS once, then thread (c, q) runs the radix-R transforms for
+// its ka and applies the 4-step twiddle.  One pass over memory for 5 or 6 bits of the transform length
+// where the register kernel above needs two (64 points of 64 bits do not fit a thread: 404-512 VGPRs).
+template <int LOGR, bool INVERSE, bool HALF>
+__global__ void __launch_bounds__(256) col64x_kernel(const Col64Args a, const ModParams64 m)
+{
+    constexpr int R = 1 << LOGR;
+    constexpr int LOGC = 8 - LOGR;
+    constexpr int C = 1 << LOGC;
+    constexpr int KA = 16 / R;
+    __shared__ uint64_t lds[4096];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t cl = tid & (C - 1);
+    const int r = __builtin_amdgcn_readfirstlane(tid >> LOGC);        // wave-uniform
+    const uint32_t c = blockIdx.x * C + cl;
+    const uint32_t S = 1u << a.logS;
+    const uint32_t i2 = c & (S - 1);
+    const uint32_t base = ((c >> a.logS) << a.logM) + i2;
+    const int op = blockIdx.z;
+    const uint64_t *__restrict__ in = a.in[op] + (size_t)blockIdx.y * a.in_stride;
+    uint64_t *__restrict__ out = a.out[op] + (size_t)blockIdx.y * a.out_stride;
+    const uint64_t *__restrict__ tw = a.tw + i2;
+
+    uint64_t x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (HALF && j >= 8) {
+            x[j] = 0;
+        } else {
+            const uint32_t row = (uint32_t)(R * j + r);
+            const uint32_t idx = base + (row << a.logS);
+            uint64_t v = idx < a.in_len ? in[idx] : 0ull;
+            if (!INVERSE && a.twist) v = M64::mulw(v, a.twist[idx], m);           // negacyclic: x[i] * psi^i
+            if constexpr (INVERSE) {
+                if (row == 0) { if (a.use_scale0) v = M64::mulw(v, a.scale0, m); }
+                else v = M64::mulw(v, tw[(size_t)row << a.logS], m);
+            }
+            x[j] = v;
+        }
+    }
+    reg_ntt64<4, HALF>(x, a.roots, m);
+    if (r != 0) {
+#pragma unroll
+        for (int ka = 1; ka < 16; ++ka) x[ka] = M64::mulw(x[ka], a.tw_in[r * 16 + ka], m);
+    }
+#pragma unroll
+    for (int ka = 0; ka < 16; ++ka) lds[(r * 16 + ka) * C + cl] = x[ka];
+    __syncthreads();
+    const int q = r;
+#pragma unroll
+    for (int j = 0; j < KA; ++j) {
+        const int ka = q * KA + j;
+        uint64_t y[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) y[rr] = lds[(rr * 16 + ka) * C + cl];
+        reg_ntt64<LOGR, false>(y, a.roots, m);
+#pragma unroll
+        for (int kr = 0; kr < R; ++kr) {
+            const uint32_t row = (uint32_t)(ka + 16 * kr);
+            const uint32_t idx = base + (row << a.logS);
+            uint64_t v = y[kr];
+            if constexpr (!INVERSE) {
+                if (row != 0) v = M64::mulw(v, tw[(size_t)row << a.logS], m);
+            } else {
+                if (a.canon && a.twist) v = M64::mulw(v, a.twist[idx], m);        // negacyclic: result * psi^-i
+            }
+            if (a.canon) v = M64::canon(v, m);
+            if (idx < a.out_len) out[idx] = v;
+        }
+    }
+}
+
+template <int LOGR>
+static void launch_col64x_t(bool inverse, bool half_in, const Col64Args &a, const ModParams64 &mp, dim3 grid, hipStream_t s)
+{
+    if (inverse) hipLaunchKernelGGL((col64x_kernel<LOGR, true, false>), grid, dim3(256), 0, s, a, mp);
+    else if (half_in) hipLaunchKernelGGL((col64x_kernel<LOGR, false, true>), grid, dim3(256), 0, s, a, mp);
+    else hipLaunchKernelGGL((col64x_kernel<LOGR, false, false>), grid, dim3(256), 0, s, a, mp);
+}
+
+void launch_col64x(int logN1, bool inverse, bool half_in, const Col64Args &a, const ModParams64 &mp,
+                   unsigned cols_per_row, unsigned batch, unsigned nops, hipStream_t s)
+{
+    if (logN1 == 6) launch_col64x_t<2>(inverse, half_in, a, mp, dim3(cols_per_row / 64, batch, nops), s);
+    else launch_col64x_t<1>(inverse, half_in, a, mp, dim3(cols_per_row / 128, batch, nops), s);
+}
+
 // ---- LDS transform of one block of len = 2^logLen <= 4096 points ---------------------------------------
 // Forward: DIF, natural in -> bit-reversed out.  w[j] = w_len^j, j < len/2.
 __device__ __forceinline__ void lds_forward64(uint64_t *lds, int logLen, const uint64_t *__restrict__ w,
