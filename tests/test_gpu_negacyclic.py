@@ -253,3 +253,38 @@ def test_negacyclic64_ring_identity_and_batch(nt, ctx):
     plan.close()
     with pytest.raises(nt.NttError):
         ctx.negacyclic_plan64(p, 1000)
+
+
+def test_randomised_shapes_all_rings(nt, ctx):
+    """Seeded sweep over ring, lane width, prime, size and batch: every combination against the linear
+    product of the oracle (folded for x^n + 1)."""
+    rng = np.random.default_rng(2025)
+    primes32 = [998244353, 469762049, 1224736769, 1004535809, 104857601, 7340033]
+    for trial in range(40):
+        lg = int(rng.integers(1, 15))
+        n = 1 << lg
+        B = int(rng.integers(1, 4))
+        p = primes32[int(rng.integers(0, len(primes32)))]
+        if (p - 1) % (2 * n):
+            continue
+        a, b = rand(rng, (B, n), p), rand(rng, (B, n), p)
+        kind = nt.MONTGOMERY if trial % 2 == 0 else nt.BARRETT
+        plan = ctx.negacyclic_plan(p, n, B, kind)
+        got = plan.multiply(a, b)
+        plan.close()
+        for i in range(B):
+            assert np.array_equal(got[i], negacyclic_from_linear(a[i], b[i], p)), (trial, n, p, kind, i)
+    for trial in range(16):
+        lg = int(rng.integers(1, 16))
+        n = 1 << lg
+        B = int(rng.integers(1, 3))
+        a = rng.integers(0, P51, size=(B, n), dtype=np.uint64)
+        b = rng.integers(0, P51, size=(B, n), dtype=np.uint64)
+        neg = trial % 2 == 0
+        plan = ctx.negacyclic_plan64(P51, n, B) if neg else ctx.plan64(P51, n, B)
+        got = plan.multiply(a, b)
+        plan.close()
+        for i in range(B):
+            lin, _ = orc.poly_multiply_crt(a[i], b[i], P51, threads=4)
+            want = fold(lin, n, P51) if neg else lin
+            assert np.array_equal(got[i], want), (trial, n, neg, i)
