@@ -11,7 +11,9 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
   roofline     -- HBM roofline of the dominant kernel, timed with HIP events inside the library on
                   the stream the kernels run on (ntt_ctx_enable_kernel_timing)
   cpu_baseline -- the CPU oracle's restatement of the reference's OpenMP path (main-openmp.cc) timed
-                  on this box's host cores on a bounded sample of the same workload (rank 0, N = 1)
+                  on this box's host cores on a bounded sample of the same workload (rank 0, N = 1);
+                  this leg is the only place the oracle is touched: it also compares its product of
+                  pair 0 with the GPU's.  Every rank checks A(x) * B(x) = AB(x) on its own output first.
 """
 import argparse
 import json
@@ -28,21 +30,43 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
+def splitmix64(seed, count):
+    """The synthetic-input generator of SURVEY 8(d): element i is the (i+1)-th splitmix64 output for `seed`."""
+    with np.errstate(over="ignore"):
+        x = np.uint64(seed & ((1 << 64) - 1)) + np.arange(1, count + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        z = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
 def splitmix_fill(seed, rows, n, p):
-    import orc
     out = np.empty((rows, n), dtype=np.uint32)
     for r in range(rows):        # SURVEY 8(d): seed 0x20250711 + pair index, next() % p
-        out[r] = (orc.splitmix64_np(seed + r, n) % np.uint64(p)).astype(np.uint32)
+        out[r] = (splitmix64(seed + r, n) % np.uint64(p)).astype(np.uint32)
     return out
 
 
-def cpu_baseline(n, p, threads, budget_s):
+def evaluation_identity(a, b, ab, p, points=(1, 3, 0x2545F491)):
+    """Oracle-free check every rank runs on its own output: A(x) * B(x) = AB(x) (mod p) at a few points."""
+    def horner(c, x):
+        acc = 0
+        for v in c[::-1].tolist():
+            acc = (acc * x + v) % p
+        return acc
+    return int(ab.max()) < p and all(horner(a, x % p) * horner(b, x % p) % p == horner(ab, x % p) for x in points)
+
+
+def cpu_baseline(n, p, threads, budget_s, gpu_row0):
     """The oracle's port of main-openmp.cc (per-stage block-parallel radix-2 NTT, 64-bit Montgomery),
-    timed between the reference's Start/End stamps.  Checker code used as the reported baseline only."""
+    timed between the reference's Start/End stamps.  Checker code used as the reported baseline only;
+    its product of pair 0 (the same seeds as row 0 of rank 0's batch) is also compared with the GPU's."""
     import orc
-    a = (orc.splitmix64_np(0x20250711, n) % np.uint64(p)).astype(np.uint64)
-    b = (orc.splitmix64_np(0x20250711 + (1 << 20), n) % np.uint64(p)).astype(np.uint64)
-    orc.poly_multiply_omp(a, b, p, threads=threads)          # warm-up
+    a = (splitmix64(0x20250711, n) % np.uint64(p)).astype(np.uint64)
+    b = (splitmix64(0x20250711 + (1 << 20), n) % np.uint64(p)).astype(np.uint64)
+    want, _ = orc.poly_multiply_omp(a, b, p, threads=threads)          # warm-up
+    if gpu_row0 is not None and not np.array_equal(np.asarray(want).astype(np.uint64), gpu_row0.astype(np.uint64)):
+        print("bench: GPU result differs from the oracle", file=sys.stderr)
+        sys.exit(1)
     t0 = time.time()
     secs, reps = 0.0, 0
     while time.time() - t0 < budget_s and reps < 200:
@@ -87,7 +111,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=0, help="products per kernel launch (0 = library default)")
     ap.add_argument("--no-check", action="store_true",
-                    help="skip the oracle spot-check (timing-only ablation builds whose results are wrong on purpose)")
+                    help="skip the result checks (timing-only ablation builds whose results are wrong on purpose)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket kernels with HIP events in the timed region (no roofline block)")
     args = ap.parse_args()
@@ -129,14 +153,16 @@ def main():
         step()
     sync()
 
-    # spot-check the warm-up output against the oracle before timing anything (rank 0)
-    if rank == 0 and not args.no_check:
-        import orc
+    # every rank checks the last product of its warm-up output before timing anything (no oracle here:
+    # the oracle comparison of pair 0 happens inside the cpu_baseline leg below)
+    gpu_row0 = None
+    if not args.no_check:
         row = B - 1
         got = dab[row, :2 * n - 1].cpu().numpy().view(np.uint32)
-        if not np.array_equal(got, orc.poly_multiply(ha[row], hb[row], p)):
-            print("bench: GPU result differs from the oracle", file=sys.stderr)
+        if not evaluation_identity(ha[row], hb[row], got, p):
+            print(f"bench: rank {rank}: A(x) * B(x) != AB(x) on the GPU result", file=sys.stderr)
             sys.exit(1)
+        gpu_row0 = dab[0, :2 * n - 1].cpu().numpy().view(np.uint32).copy()
 
     # which kernel dominates (all kernels bracketed with events over two untimed steps); the timed region
     # then pays only for the events of the kernel it reports
@@ -212,7 +238,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(n, p, threads, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(n, p, threads, args.cpu_seconds, gpu_row0)
         print(json.dumps(out), flush=True)
 
     plan.close()
