@@ -6,7 +6,10 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
+
+import orc
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -22,3 +25,53 @@ def test_ranks_on_one_gpu(tmp_path, world):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-3000:]
     assert out.read_text() == "ok"
+
+
+def _write_case(data, cid, n, p, a, b, ab):
+    with open(data / f"{cid}.in", "w") as f:              # the reference's layout
+        f.write(f"{n} {p}\n" + "".join(f"{v} " for v in a) + "\n" + "".join(f"{v} " for v in b))
+    with open(data / f"{cid}.out", "w") as f:
+        f.write("".join(f"{v} " for v in ab))
+
+
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (1, "gloo"), (2, "gloo"), (4, "gloo")])
+def test_launcher_rank_layout(tmp_path, nttdata, world, backend):
+    """python -m ntt_amd.launch = main() of main-mpi.cc:642-819 with one process per rank: rank 0 reads and
+    broadcasts, 32-bit cases run on rank 0, the 51-bit case shards its four primes over the ranks.  Cases 0
+    and 1 are the reference's own (golden outputs; "nccl" at one rank = the device-tensor route without a peer); case 2 is a 33-bit prime (64-bit lanes on rank 0), case 4
+    the reference's 51-bit modulus on synthetic operands with the CRT oracle's product as <id>.out."""
+    data, out = tmp_path / "nttdata", tmp_path / "files"
+    data.mkdir()
+    out.mkdir()
+    for cid in (0, 1):
+        _write_case(data, cid, *nttdata[cid])
+    rng = np.random.default_rng(40 + world)
+    expected = {}
+    for cid, p, n in ((2, 8588886017, 700), (4, 1337006139375617, 3001)):
+        a = rng.integers(0, p, size=n, dtype=np.uint64)
+        b = rng.integers(0, p, size=n, dtype=np.uint64)
+        ab, _ = orc.poly_multiply_crt(a, b, p, threads=2)
+        _write_case(data, cid, n, p, a, b, ab)
+        expected[cid] = ab
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2",
+               PYTHONPATH=os.path.dirname(HERE) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29580 + world),
+           "-m", "ntt_amd.launch", "--data", str(data), "--out", str(out), "--begin", "0", "--end", "4",
+           "--epochs", "3", "--backend", backend]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 1, r.stderr[-3000:]              # case 3 is missing: reported in the exit status
+    assert "case 3 skipped" in r.stderr
+    lines = r.stdout.strip().split("\n")
+    assert lines.count("多项式乘法结果正确") == 4 and "多项式乘法结果错误" not in r.stdout
+    assert any(l.startswith("average latency for n = 3001 p = 1337006139375617 : ") and l.endswith(" (us)")
+               for l in lines)
+    assert np.array_equal(np.loadtxt(out / "1.out", dtype=np.uint64).astype(np.uint32), nttdata[1][4])
+    for cid, ab in expected.items():
+        assert np.array_equal(np.loadtxt(out / f"{cid}.out", dtype=np.uint64), ab)
+    # a wrong expected output flips the verdict and the exit status
+    (data / "3.in").write_text((data / "0.in").read_text())
+    (data / "3.out").write_text("1 2 3 4 5 6 7 ")
+    r = subprocess.run(cmd[:-8] + ["--begin", "3", "--end", "3", "--epochs", "1", "--backend", backend],
+                       env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 1 and "多项式乘法结果错误" in r.stdout
