@@ -78,7 +78,17 @@ bool is_prime64(uint64_t n)
     }
     return true;
 }
-uint64_t to_mont(uint64_t x, const ModParams64 &mp) { return (uint64_t)((((u128)x) << 64) % mp.p); }
+// table entry for the residue x: Montgomery form, or the residue itself as a double (F64 policy)
+uint64_t to_mont(uint64_t x, const ModParams64 &mp)
+{
+    if (mp.fp) {
+        const double d = (double)x;                     // x < p < 2^51: exact
+        uint64_t bits;
+        std::memcpy(&bits, &d, 8);
+        return bits;
+    }
+    return (uint64_t)((((u128)x) << 64) % mp.p);
+}
 
 ModParams64 make_params(uint64_t p)
 {
@@ -90,6 +100,13 @@ ModParams64 make_params(uint64_t p)
     m.nprime = 0 - inv;
     m.r1 = (uint64_t)((((u128)1) << 64) % p);
     m.r2 = mulmod(m.r1, m.r1, p);
+    // p < 2^51: exact integer arithmetic in double-precision lanes (kernels_u64.hip, F64); NTT_AMD_PLAN64_INT=1
+    // keeps such a prime on the Montgomery lanes (A/B runs, tests of both policies on one prime)
+    const char *e = std::getenv("NTT_AMD_PLAN64_INT");
+    m.fp = (p < (1ull << 51) && !(e && std::atoi(e) != 0)) ? 1 : 0;
+    m.pd = (double)p;
+    m.pinv = 1.0 / (double)p;
+    if (m.fp) m.r1 = 1;                                 // no Montgomery factor to cancel in the scale
     return m;
 }
 
@@ -208,6 +225,7 @@ Col64Args fill_col(ntt_plan64 *pl, int level, bool inverse, const uint64_t *in0,
     a.use_scale0 = (inverse && level == pl->nlevels - 1) ? 1 : 0;
     a.scale0 = pl->scale;
     a.canon = canon ? 1 : 0;
+    a.ext_in = (!inverse && level == 0) ? 1 : 0;
     a.roots = inverse ? pl->iroots : pl->roots;
     a.twist = (pl->negacyclic && level == 0) ? (inverse ? pl->twist_inv : pl->twist_fwd) : nullptr;
     if (pl->level_log[level] >= 5) {
@@ -232,7 +250,7 @@ int multiply_device(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64
         r.in_len = n; r.out_len = out_len;
         r.blocks_per_row = 1; r.logLen = pl->logL;
         r.w = pl->row_w; r.iw = pl->row_iw;
-        r.scale = pl->scale; r.use_scale = 1; r.canon = 1; r.mode = 0;
+        r.scale = pl->scale; r.use_scale = 1; r.canon = 1; r.mode = 0; r.ext_in = 1;
         if (neg) { r.twist = pl->twist_fwd; r.itwist = pl->small_itwist; }
         cx->begin(K_LDS64);
         launch_lds64(r, pl->mp, (unsigned)batch, s);

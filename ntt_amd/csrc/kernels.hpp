@@ -154,6 +154,8 @@ void launch_crt_merge(const uint32_t *const res[4], uint64_t *out, size_t n, con
 struct ModParams64 {
     uint64_t p, p2, nprime;              // nprime = -p^-1 mod 2^64
     uint64_t r1, r2;                     // 2^64 mod p, 2^128 mod p (host side: table construction)
+    double pd, pinv;                     // F64 policy (p < 2^51): p and 1/p as doubles
+    uint32_t fp;                         // 1: the F64 policy runs (tables hold doubles), 0: Montgomery lanes
 };
 struct Roots16x64 {
     uint64_t w[8];                       // w_16^j (forward) or w_16^-j (inverse), Montgomery form
@@ -167,7 +169,8 @@ struct Col64Args {
     const uint64_t *tw;                  // [N1][S] 4-step twiddles, Montgomery form
     uint64_t scale0;
     int use_scale0;
-    int canon;
+    int canon;                           // output is the caller's: canonical u64 residues
+    int ext_in;                          // input is the caller's (u64 residues < p), not an intermediate
     Roots16x64 roots;
     const uint64_t *twist;               // negacyclic: [L] psi^(+-i), Montgomery form; nullptr otherwise
     uint64_t tw_in[64];                  // LDS-staged levels of 32 / 64 points: w_N1^(+-r*ka), index r*16 + ka
@@ -182,6 +185,7 @@ struct Lds64Args {
     const uint64_t *w, *iw;              // w_len^j, w_len^-j, j < len/2, Montgomery form
     uint64_t scale;
     int use_scale, canon, mode;          // mode 0 multiply, 1 forward, 2 inverse
+    int ext_in;                          // input is the caller's (u64 residues < p)
     const uint64_t *twist, *itwist;      // negacyclic multiply: psi^i, and psi^-i with the scale folded in
 };
 struct Row64Args {

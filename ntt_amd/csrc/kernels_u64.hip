@@ -15,11 +15,28 @@
 // lds64_kernel: radix-2 in LDS, decimation in frequency forward (natural in, bit-reversed out),
 // decimation in time inverse (bit-reversed in, natural out), pointwise product in between.  Neither
 // needs a reordering pass.
+//
+// Two arithmetic policies run the same kernels (template parameter A):
+//   M64  the Montgomery lanes above, any p < 2^62;
+//   F64  for p < 2^51: residues as exact integers in double-precision lanes, |x| <= p.  x * w mod p is
+//        h = x*w (rounded), l = fma(x, w, -h) (its exact error), q = rint(h / p), r = fma(-q, p, h) + l.
+//        With |x| <= 2p, |w| <= p: |x*w/p| < 2^52, the three roundings behind q (1/p, h, h * 1/p)
+//        move it by < 1.5, rint by 0.5, so |x*w - q*p| < 2p < 2^52: the fma result and the sum are exact
+//        integers; one fold (r - copysign(p, r)) brings |r| back to <= p.  Sums and differences of two
+//        values stay below 2^52, exact as well.  Eight full-rate FP64 instructions per multiplication
+//        against eleven 32x32 multiply-adds plus carries, three per modular add against seven.
+//        Tables hold plain residues as doubles (no Montgomery factor).  Operands must be < p.
 #include "kernels.hpp"
 
 namespace ntt {
 
 struct M64 {
+    using T = uint64_t;
+    static __device__ __forceinline__ T zero() { return 0; }
+    static __device__ __forceinline__ T ext_in(uint64_t v, const ModParams64 &) { return v; }     // caller's residue
+    static __device__ __forceinline__ T raw(uint64_t bits) { return bits; }                       // table entry / intermediate
+    static __device__ __forceinline__ uint64_t bits(T v) { return v; }
+    static __device__ __forceinline__ uint64_t canon_bits(T v, const ModParams64 &m) { return csub(v, m.p); }
     static __device__ __forceinline__ uint64_t csub(uint64_t x, uint64_t m)
     {
         const uint64_t d = x - m;
@@ -58,7 +75,39 @@ struct M64 {
     {
         return u - v + m.p2;                // (0, 4p): valid mulw operand
     }
-    static __device__ __forceinline__ uint64_t canon(uint64_t x, const ModParams64 &m) { return csub(x, m.p); }
+};
+
+struct F64 {
+    using T = double;
+    static __device__ __forceinline__ T zero() { return 0.0; }
+    // u64 < 2^52 <-> double through the 2^52 offset (exponent bits 0x433)
+    static __device__ __forceinline__ T ext_in(uint64_t v, const ModParams64 &)
+    {
+        return __builtin_bit_cast(double, v | 0x4330000000000000ull) - 0x1p52;
+    }
+    static __device__ __forceinline__ T raw(uint64_t bits) { return __builtin_bit_cast(double, bits); }
+    static __device__ __forceinline__ uint64_t bits(T v) { return __builtin_bit_cast(uint64_t, v); }
+    static __device__ __forceinline__ uint64_t canon_bits(T v, const ModParams64 &m)
+    {
+        double t = v < 0.0 ? v + m.pd : v;          // [0, p]
+        t = t >= m.pd ? t - m.pd : t;               // [0, p)
+        return __builtin_bit_cast(uint64_t, t + 0x1p52) & 0x000fffffffffffffull;
+    }
+    static __device__ __forceinline__ T fold(T s, const ModParams64 &m)      // |s| <= 2p  ->  |s| <= p
+    {
+        return s - __builtin_copysign(m.pd, s);
+    }
+    static __device__ __forceinline__ T mulw(T x, T w, const ModParams64 &m)  // |x| <= 2p, |w| <= p
+    {
+        const double h = x * w;
+        const double l = __builtin_fma(x, w, -h);
+        const double q = __builtin_rint(h * m.pinv);
+        const double r = __builtin_fma(-q, m.pd, h) + l;
+        return fold(r, m);
+    }
+    static __device__ __forceinline__ T add(T u, T v, const ModParams64 &m) { return fold(u + v, m); }
+    static __device__ __forceinline__ T sub(T u, T v, const ModParams64 &m) { return fold(u - v, m); }
+    static __device__ __forceinline__ T sub_raw(T u, T v, const ModParams64 &) { return u - v; }
 };
 
 __host__ __device__ constexpr int bitrev64_c(int x, int bits)
@@ -70,9 +119,10 @@ __host__ __device__ constexpr int bitrev64_c(int x, int bits)
 
 // N-point transform in registers, N = 2^LOGN <= 16, natural in / natural out, values in [0, 2p).
 // roots.w[j] = w_16^j (forward or inverse table), so w_(2*half)^j = w[j * 8 / half].
-template <int LOGN, bool HALF>
-__device__ __forceinline__ void reg_ntt64(uint64_t (&x)[1 << LOGN], const Roots16x64 &roots, const ModParams64 &m)
+template <class A, int LOGN, bool HALF>
+__device__ __forceinline__ void reg_ntt64(typename A::T (&x)[1 << LOGN], const Roots16x64 &roots, const ModParams64 &m)
 {
+    using T = typename A::T;
     constexpr int N = 1 << LOGN;
 #pragma unroll
     for (int s = 0; s < LOGN; ++s) {
@@ -82,17 +132,17 @@ __device__ __forceinline__ void reg_ntt64(uint64_t (&x)[1 << LOGN], const Roots1
         for (int blk = 0; blk < N; blk += 2 * half) {
 #pragma unroll
             for (int j = 0; j < half; ++j) {
-                const uint64_t u = x[blk + j], v = x[blk + j + half];
+                const T u = x[blk + j], v = x[blk + j + half];
                 if (HALF && s == 0) {
-                    x[blk + j + half] = j == 0 ? u : M64::mulw(u, roots.w[j * step], m);   // v == 0
+                    x[blk + j + half] = j == 0 ? u : A::mulw(u, A::raw(roots.w[j * step]), m);   // v == 0
                 } else {
-                    x[blk + j] = M64::add(u, v, m);
-                    x[blk + j + half] = j == 0 ? M64::sub(u, v, m) : M64::mulw(M64::sub_raw(u, v, m), roots.w[j * step], m);
+                    x[blk + j] = A::add(u, v, m);
+                    x[blk + j + half] = j == 0 ? A::sub(u, v, m) : A::mulw(A::sub_raw(u, v, m), A::raw(roots.w[j * step]), m);
                 }
             }
         }
     }
-    uint64_t y[N];
+    T y[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) y[bitrev64_c(i, LOGN)] = x[i];
 #pragma unroll
@@ -101,9 +151,10 @@ __device__ __forceinline__ void reg_ntt64(uint64_t (&x)[1 << LOGN], const Roots1
 
 // ---- column pass ---------------------------------------------------------------------------------------
 // One thread per column of a block viewed as N1 x S (index maps as kernels_col.hip).
-template <int LOGN1, bool INVERSE, bool HALF>
+template <class A, int LOGN1, bool INVERSE, bool HALF>
 __global__ void __launch_bounds__(256) col64_kernel(const Col64Args a, const ModParams64 m)
 {
+    using T = typename A::T;
     constexpr int N1 = 1 << LOGN1;
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
     const uint32_t S = 1u << a.logS;
@@ -114,60 +165,68 @@ __global__ void __launch_bounds__(256) col64_kernel(const Col64Args a, const Mod
     uint64_t *__restrict__ out = a.out[op] + (size_t)blockIdx.y * a.out_stride;
     const uint64_t *__restrict__ tw = a.tw + i2;
 
-    uint64_t x[N1];
+    T x[N1];
 #pragma unroll
     for (int i1 = 0; i1 < N1; ++i1) {
         if (HALF && i1 >= N1 / 2) {
-            x[i1] = 0;
+            x[i1] = A::zero();
         } else {
             const uint32_t idx = base + ((uint32_t)i1 << a.logS);
-            x[i1] = idx < a.in_len ? in[idx] : 0ull;
+            const uint64_t v = idx < a.in_len ? in[idx] : 0ull;
+            x[i1] = a.ext_in ? A::ext_in(v, m) : A::raw(v);
         }
     }
     if (!INVERSE && a.twist) {                                // negacyclic: x[i] * psi^i (uniform branch)
 #pragma unroll
         for (int i1 = 0; i1 < N1; ++i1)
-            if (!(HALF && i1 >= N1 / 2)) x[i1] = M64::mulw(x[i1], a.twist[base + ((uint32_t)i1 << a.logS)], m);
+            if (!(HALF && i1 >= N1 / 2)) x[i1] = A::mulw(x[i1], A::raw(a.twist[base + ((uint32_t)i1 << a.logS)]), m);
     }
     if constexpr (INVERSE) {
-        if (a.use_scale0) x[0] = M64::mulw(x[0], a.scale0, m);
+        if (a.use_scale0) x[0] = A::mulw(x[0], A::raw(a.scale0), m);
 #pragma unroll
-        for (int k1 = 1; k1 < N1; ++k1) x[k1] = M64::mulw(x[k1], tw[(size_t)k1 << a.logS], m);
+        for (int k1 = 1; k1 < N1; ++k1) x[k1] = A::mulw(x[k1], A::raw(tw[(size_t)k1 << a.logS]), m);
     }
-    reg_ntt64<LOGN1, HALF>(x, a.roots, m);
+    reg_ntt64<A, LOGN1, HALF>(x, a.roots, m);
     if constexpr (!INVERSE) {
 #pragma unroll
-        for (int k1 = 1; k1 < N1; ++k1) x[k1] = M64::mulw(x[k1], tw[(size_t)k1 << a.logS], m);
+        for (int k1 = 1; k1 < N1; ++k1) x[k1] = A::mulw(x[k1], A::raw(tw[(size_t)k1 << a.logS]), m);
     }
 #pragma unroll
     for (int k1 = 0; k1 < N1; ++k1) {
         const uint32_t idx = base + ((uint32_t)k1 << a.logS);
-        uint64_t v = x[k1];
-        if (INVERSE && a.canon && a.twist) v = M64::mulw(v, a.twist[idx], m);      // negacyclic: result * psi^-i
-        if (a.canon) v = M64::canon(v, m);
-        if (idx < a.out_len) out[idx] = v;
+        T v = x[k1];
+        if (INVERSE && a.canon && a.twist) v = A::mulw(v, A::raw(a.twist[idx]), m);      // negacyclic: result * psi^-i
+        if (idx < a.out_len) out[idx] = a.canon ? A::canon_bits(v, m) : A::bits(v);
     }
 }
 
-template <int LOGN1>
+template <class A, int LOGN1>
 static void launch_col64_t(bool inverse, bool half_in, const Col64Args &a, const ModParams64 &mp, dim3 grid, hipStream_t s)
 {
-    if (inverse) hipLaunchKernelGGL((col64_kernel<LOGN1, true, false>), grid, dim3(256), 0, s, a, mp);
-    else if (half_in) hipLaunchKernelGGL((col64_kernel<LOGN1, false, true>), grid, dim3(256), 0, s, a, mp);
-    else hipLaunchKernelGGL((col64_kernel<LOGN1, false, false>), grid, dim3(256), 0, s, a, mp);
+    if (inverse) hipLaunchKernelGGL((col64_kernel<A, LOGN1, true, false>), grid, dim3(256), 0, s, a, mp);
+    else if (half_in) hipLaunchKernelGGL((col64_kernel<A, LOGN1, false, true>), grid, dim3(256), 0, s, a, mp);
+    else hipLaunchKernelGGL((col64_kernel<A, LOGN1, false, false>), grid, dim3(256), 0, s, a, mp);
+}
+
+template <class A>
+static void launch_col64_a(int logN1, bool inverse, bool half_in, const Col64Args &a, const ModParams64 &mp, dim3 grid,
+                           hipStream_t s)
+{
+    switch (logN1) {
+    case 1: launch_col64_t<A, 1>(inverse, half_in, a, mp, grid, s); break;
+    case 2: launch_col64_t<A, 2>(inverse, half_in, a, mp, grid, s); break;
+    case 3: launch_col64_t<A, 3>(inverse, half_in, a, mp, grid, s); break;
+    case 4: launch_col64_t<A, 4>(inverse, half_in, a, mp, grid, s); break;
+    default: break;
+    }
 }
 
 void launch_col64(int logN1, bool inverse, bool half_in, const Col64Args &a, const ModParams64 &mp,
                   unsigned cols_per_row, unsigned batch, unsigned nops, hipStream_t s)
 {
     const dim3 grid(cols_per_row / 256, batch, nops);
-    switch (logN1) {
-    case 1: launch_col64_t<1>(inverse, half_in, a, mp, grid, s); break;
-    case 2: launch_col64_t<2>(inverse, half_in, a, mp, grid, s); break;
-    case 3: launch_col64_t<3>(inverse, half_in, a, mp, grid, s); break;
-    case 4: launch_col64_t<4>(inverse, half_in, a, mp, grid, s); break;
-    default: break;
-    }
+    if (mp.fp) launch_col64_a<F64>(logN1, inverse, half_in, a, mp, grid, s);
+    else launch_col64_a<M64>(logN1, inverse, half_in, a, mp, grid, s);
 }
 
 // ---- LDS-staged column level: N1 = 16 * R points, R = 2 or 4 -------------------------------------------------
@@ -176,9 +235,10 @@ void launch_col64(int logN1, bool inverse, bool half_in, const Col64Args &a, con
 // w_N1^(r*ka), the 32 KiB tile goes through LDS once, then thread (c, q) runs the radix-R transforms for
 // its ka and applies the 4-step twiddle.  One pass over memory for 5 or 6 bits of the transform length
 // where the register kernel above needs two (64 points of 64 bits do not fit a thread: 404-512 VGPRs).
-template <int LOGR, bool INVERSE, bool HALF>
+template <class A, int LOGR, bool INVERSE, bool HALF>
 __global__ void __launch_bounds__(256) col64x_kernel(const Col64Args a, const ModParams64 m)
 {
+    using T = typename A::T;
     constexpr int R = 1 << LOGR;
     constexpr int LOGC = 8 - LOGR;
     constexpr int C = 1 << LOGC;
@@ -196,72 +256,89 @@ __global__ void __launch_bounds__(256) col64x_kernel(const Col64Args a, const Mo
     uint64_t *__restrict__ out = a.out[op] + (size_t)blockIdx.y * a.out_stride;
     const uint64_t *__restrict__ tw = a.tw + i2;
 
-    uint64_t x[16];
+    // forward: the 4-step twiddles of this thread's 16 outputs (rows ka + 16 kr, ka = r*KA + j) are fetched
+    // up front, in flight together with the data loads, not after the exchange
+    uint64_t twv[INVERSE ? 1 : 16];
+    if constexpr (!INVERSE) {
+#pragma unroll
+        for (int j = 0; j < KA; ++j)
+#pragma unroll
+            for (int kr = 0; kr < R; ++kr)
+                twv[j * R + kr] = tw[(size_t)(r * KA + j + 16 * kr) << a.logS];
+    }
+    T x[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         if (HALF && j >= 8) {
-            x[j] = 0;
+            x[j] = A::zero();
         } else {
             const uint32_t row = (uint32_t)(R * j + r);
             const uint32_t idx = base + (row << a.logS);
-            uint64_t v = idx < a.in_len ? in[idx] : 0ull;
-            if (!INVERSE && a.twist) v = M64::mulw(v, a.twist[idx], m);           // negacyclic: x[i] * psi^i
+            const uint64_t vb = idx < a.in_len ? in[idx] : 0ull;
+            T v = a.ext_in ? A::ext_in(vb, m) : A::raw(vb);
+            if (!INVERSE && a.twist) v = A::mulw(v, A::raw(a.twist[idx]), m);           // negacyclic: x[i] * psi^i
             if constexpr (INVERSE) {
-                if (row == 0) { if (a.use_scale0) v = M64::mulw(v, a.scale0, m); }
-                else v = M64::mulw(v, tw[(size_t)row << a.logS], m);
+                if (row == 0) { if (a.use_scale0) v = A::mulw(v, A::raw(a.scale0), m); }
+                else v = A::mulw(v, A::raw(tw[(size_t)row << a.logS]), m);
             }
             x[j] = v;
         }
     }
-    reg_ntt64<4, HALF>(x, a.roots, m);
+    reg_ntt64<A, 4, HALF>(x, a.roots, m);
     if (r != 0) {
 #pragma unroll
-        for (int ka = 1; ka < 16; ++ka) x[ka] = M64::mulw(x[ka], a.tw_in[r * 16 + ka], m);
+        for (int ka = 1; ka < 16; ++ka) x[ka] = A::mulw(x[ka], A::raw(a.tw_in[r * 16 + ka]), m);
     }
 #pragma unroll
-    for (int ka = 0; ka < 16; ++ka) lds[(r * 16 + ka) * C + cl] = x[ka];
+    for (int ka = 0; ka < 16; ++ka) lds[(r * 16 + ka) * C + cl] = A::bits(x[ka]);
     __syncthreads();
     const int q = r;
 #pragma unroll
     for (int j = 0; j < KA; ++j) {
         const int ka = q * KA + j;
-        uint64_t y[R];
+        T y[R];
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) y[rr] = lds[(rr * 16 + ka) * C + cl];
-        reg_ntt64<LOGR, false>(y, a.roots, m);
+        for (int rr = 0; rr < R; ++rr) y[rr] = A::raw(lds[(rr * 16 + ka) * C + cl]);
+        reg_ntt64<A, LOGR, false>(y, a.roots, m);
 #pragma unroll
         for (int kr = 0; kr < R; ++kr) {
             const uint32_t row = (uint32_t)(ka + 16 * kr);
             const uint32_t idx = base + (row << a.logS);
-            uint64_t v = y[kr];
+            T v = y[kr];
             if constexpr (!INVERSE) {
-                if (row != 0) v = M64::mulw(v, tw[(size_t)row << a.logS], m);
+                if (row != 0) v = A::mulw(v, A::raw(twv[j * R + kr]), m);
             } else {
-                if (a.canon && a.twist) v = M64::mulw(v, a.twist[idx], m);        // negacyclic: result * psi^-i
+                if (a.canon && a.twist) v = A::mulw(v, A::raw(a.twist[idx]), m);        // negacyclic: result * psi^-i
             }
-            if (a.canon) v = M64::canon(v, m);
-            if (idx < a.out_len) out[idx] = v;
+            if (idx < a.out_len) out[idx] = a.canon ? A::canon_bits(v, m) : A::bits(v);
         }
     }
 }
 
-template <int LOGR>
+template <class A, int LOGR>
 static void launch_col64x_t(bool inverse, bool half_in, const Col64Args &a, const ModParams64 &mp, dim3 grid, hipStream_t s)
 {
-    if (inverse) hipLaunchKernelGGL((col64x_kernel<LOGR, true, false>), grid, dim3(256), 0, s, a, mp);
-    else if (half_in) hipLaunchKernelGGL((col64x_kernel<LOGR, false, true>), grid, dim3(256), 0, s, a, mp);
-    else hipLaunchKernelGGL((col64x_kernel<LOGR, false, false>), grid, dim3(256), 0, s, a, mp);
+    if (inverse) hipLaunchKernelGGL((col64x_kernel<A, LOGR, true, false>), grid, dim3(256), 0, s, a, mp);
+    else if (half_in) hipLaunchKernelGGL((col64x_kernel<A, LOGR, false, true>), grid, dim3(256), 0, s, a, mp);
+    else hipLaunchKernelGGL((col64x_kernel<A, LOGR, false, false>), grid, dim3(256), 0, s, a, mp);
 }
 
 void launch_col64x(int logN1, bool inverse, bool half_in, const Col64Args &a, const ModParams64 &mp,
                    unsigned cols_per_row, unsigned batch, unsigned nops, hipStream_t s)
 {
-    if (logN1 == 6) launch_col64x_t<2>(inverse, half_in, a, mp, dim3(cols_per_row / 64, batch, nops), s);
-    else launch_col64x_t<1>(inverse, half_in, a, mp, dim3(cols_per_row / 128, batch, nops), s);
+    const dim3 grid(cols_per_row / (logN1 == 6 ? 64 : 128), batch, nops);
+    if (logN1 == 6) {
+        if (mp.fp) launch_col64x_t<F64, 2>(inverse, half_in, a, mp, grid, s);
+        else launch_col64x_t<M64, 2>(inverse, half_in, a, mp, grid, s);
+    } else {
+        if (mp.fp) launch_col64x_t<F64, 1>(inverse, half_in, a, mp, grid, s);
+        else launch_col64x_t<M64, 1>(inverse, half_in, a, mp, grid, s);
+    }
 }
 
 // ---- LDS transform of one block of len = 2^logLen <= 4096 points ---------------------------------------
 // Forward: DIF, natural in -> bit-reversed out.  w[j] = w_len^j, j < len/2.
+template <class A>
 __device__ __forceinline__ void lds_forward64(uint64_t *lds, int logLen, const uint64_t *__restrict__ w,
                                               const ModParams64 &m)
 {
@@ -271,15 +348,16 @@ __device__ __forceinline__ void lds_forward64(uint64_t *lds, int logLen, const u
         for (uint32_t idx = threadIdx.x; idx < nb; idx += 256) {
             const uint32_t j = idx & ((1u << lh) - 1);
             const uint32_t i0 = ((idx >> lh) << (lh + 1)) + j, i1 = i0 + (1u << lh);
-            const uint64_t u = lds[i0], v = lds[i1];
-            lds[i0] = M64::add(u, v, m);
-            lds[i1] = M64::mulw(M64::sub_raw(u, v, m), w[j << s], m);
+            const typename A::T u = A::raw(lds[i0]), v = A::raw(lds[i1]);
+            lds[i0] = A::bits(A::add(u, v, m));
+            lds[i1] = A::bits(A::mulw(A::sub_raw(u, v, m), A::raw(w[j << s]), m));
         }
         __syncthreads();
     }
 }
 
 // Inverse: DIT, bit-reversed in -> natural out, unscaled.  iw[j] = w_len^-j.
+template <class A>
 __device__ __forceinline__ void lds_inverse64(uint64_t *lds, int logLen, const uint64_t *__restrict__ iw,
                                               const ModParams64 &m)
 {
@@ -289,9 +367,9 @@ __device__ __forceinline__ void lds_inverse64(uint64_t *lds, int logLen, const u
         for (uint32_t idx = threadIdx.x; idx < nb; idx += 256) {
             const uint32_t j = idx & ((1u << lh) - 1);
             const uint32_t i0 = ((idx >> lh) << (lh + 1)) + j, i1 = i0 + (1u << lh);
-            const uint64_t u = lds[i0], v = M64::mulw(lds[i1], iw[j << s], m);
-            lds[i0] = M64::add(u, v, m);
-            lds[i1] = M64::sub(u, v, m);
+            const typename A::T u = A::raw(lds[i0]), v = A::mulw(A::raw(lds[i1]), A::raw(iw[j << s]), m);
+            lds[i0] = A::bits(A::add(u, v, m));
+            lds[i1] = A::bits(A::sub(u, v, m));
         }
         __syncthreads();
     }
@@ -301,8 +379,10 @@ __device__ __forceinline__ void lds_inverse64(uint64_t *lds, int logLen, const u
 // (bit-reversed order on the spectrum side in every mode).  One workgroup per block of len points;
 // blocks_per_row blocks make one batch row (1 for the whole-transform case L <= 4096, L/4096 rows
 // otherwise).  `scale` (Montgomery form) multiplies the output when use_scale is set.
+template <class A>
 __global__ void __launch_bounds__(256) lds64_kernel(const Lds64Args a, const ModParams64 m)
 {
+    using T = typename A::T;
     __shared__ uint64_t lds[4096];
     const uint32_t len = 1u << a.logLen;
     const uint32_t blk = blockIdx.x % a.blocks_per_row, row = blockIdx.x / a.blocks_per_row;
@@ -313,15 +393,16 @@ __global__ void __launch_bounds__(256) lds64_kernel(const Lds64Args a, const Mod
 
     const bool neg = a.mode == 0 && a.twist != nullptr;       // negacyclic multiply (whole transform in this block)
     for (uint32_t i = threadIdx.x; i < len; i += 256) {
-        uint64_t v = (off + i) < in_len ? pa[i] : 0ull;
-        if (neg) v = M64::mulw(v, a.twist[i], m);
-        lds[i] = v;
+        const uint64_t vb = (off + i) < in_len ? pa[i] : 0ull;
+        T v = a.ext_in ? A::ext_in(vb, m) : A::raw(vb);
+        if (neg) v = A::mulw(v, A::raw(a.twist[i]), m);
+        lds[i] = A::bits(v);
     }
     __syncthreads();
     if (a.mode == 2) {
-        lds_inverse64(lds, a.logLen, a.iw, m);
+        lds_inverse64<A>(lds, a.logLen, a.iw, m);
     } else {
-        lds_forward64(lds, a.logLen, a.w, m);
+        lds_forward64<A>(lds, a.logLen, a.w, m);
         if (a.mode == 0) {
             const uint64_t *__restrict__ pb = a.b + (size_t)row * a.in_stride + off;
             uint64_t ra[16];
@@ -332,28 +413,28 @@ __global__ void __launch_bounds__(256) lds64_kernel(const Lds64Args a, const Mod
             }
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < len; i += 256) {
-                uint64_t v = (off + i) < in_len ? pb[i] : 0ull;
-                if (neg) v = M64::mulw(v, a.twist[i], m);
-                lds[i] = v;
+                const uint64_t vb = (off + i) < in_len ? pb[i] : 0ull;
+                T v = a.ext_in ? A::ext_in(vb, m) : A::raw(vb);
+                if (neg) v = A::mulw(v, A::raw(a.twist[i]), m);
+                lds[i] = A::bits(v);
             }
             __syncthreads();
-            lds_forward64(lds, a.logLen, a.w, m);
+            lds_forward64<A>(lds, a.logLen, a.w, m);
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const uint32_t i = threadIdx.x + 256u * k;
-                // REDC(a*b): a, b < 2p, a*b < 2^64 * p; the stray R^-1 is folded into the scale
-                if (i < len) lds[i] = M64::mulw(ra[k], lds[i], m);
+                // M64: REDC(a*b), a, b < 2p, a*b < 2^64 * p; the stray R^-1 is folded into the scale
+                if (i < len) lds[i] = A::bits(A::mulw(A::raw(ra[k]), A::raw(lds[i]), m));
             }
             __syncthreads();
-            lds_inverse64(lds, a.logLen, a.iw, m);
+            lds_inverse64<A>(lds, a.logLen, a.iw, m);
         }
     }
     for (uint32_t i = threadIdx.x; i < len; i += 256) {
-        uint64_t v = lds[i];
-        if (neg) v = M64::mulw(v, a.itwist[i], m);            // psi^-i with the scale folded in
-        else if (a.use_scale) v = M64::mulw(v, a.scale, m);
-        if (a.canon) v = M64::canon(v, m);
-        if ((off + i) < out_len) po[i] = v;
+        T v = A::raw(lds[i]);
+        if (neg) v = A::mulw(v, A::raw(a.itwist[i]), m);            // psi^-i with the scale folded in
+        else if (a.use_scale) v = A::mulw(v, A::raw(a.scale), m);
+        if ((off + i) < out_len) po[i] = a.canon ? A::canon_bits(v, m) : A::bits(v);
     }
 }
 
@@ -367,87 +448,93 @@ constexpr int kRow64Words = kRowLen + kRowLen / 16;          // 4352 x 8 B = 34 
 __device__ __forceinline__ uint32_t Q1(uint32_t i) { return i + ((i >> 8) << 4); }
 __device__ __forceinline__ uint32_t Q2(uint32_t i) { return i + (i >> 4); }
 
-__device__ __forceinline__ void row64_forward(uint64_t (&x)[16], uint64_t *lds, const uint32_t t, const Row64Args &a,
+template <class A>
+__device__ __forceinline__ void row64_forward(typename A::T (&x)[16], uint64_t *lds, const uint32_t t, const Row64Args &a,
                                               const ModParams64 &m)
 {
-    reg_ntt64<4, false>(x, a.roots, m);
+    reg_ntt64<A, 4, false>(x, a.roots, m);
 #pragma unroll
-    for (int k = 1; k < 16; ++k) x[k] = M64::mulw(x[k], a.twA[k * 256 + t], m);
+    for (int k = 1; k < 16; ++k) x[k] = A::mulw(x[k], A::raw(a.twA[k * 256 + t]), m);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) lds[Q1(k * 256 + t)] = x[k];
+    for (int k = 0; k < 16; ++k) lds[Q1(k * 256 + t)] = A::bits(x[k]);
     __syncthreads();
     const uint32_t b = t >> 4, i = t & 15;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) x[j] = lds[Q1(b * 256 + j * 16 + i)];
+    for (int j = 0; j < 16; ++j) x[j] = A::raw(lds[Q1(b * 256 + j * 16 + i)]);
     __syncthreads();
-    reg_ntt64<4, false>(x, a.roots, m);
+    reg_ntt64<A, 4, false>(x, a.roots, m);
 #pragma unroll
-    for (int k = 1; k < 16; ++k) x[k] = M64::mulw(x[k], a.twB[k * 16 + i], m);
+    for (int k = 1; k < 16; ++k) x[k] = A::mulw(x[k], A::raw(a.twB[k * 16 + i]), m);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) lds[Q2(b * 256 + k * 16 + i)] = x[k];
+    for (int k = 0; k < 16; ++k) lds[Q2(b * 256 + k * 16 + i)] = A::bits(x[k]);
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 16; ++j) x[j] = lds[Q2(t * 16 + j)];
+    for (int j = 0; j < 16; ++j) x[j] = A::raw(lds[Q2(t * 16 + j)]);
     __syncthreads();
-    reg_ntt64<4, false>(x, a.roots, m);
+    reg_ntt64<A, 4, false>(x, a.roots, m);
 }
 
-__device__ __forceinline__ void row64_inverse(uint64_t (&x)[16], uint64_t *lds, const uint32_t t, const Row64Args &a,
+template <class A>
+__device__ __forceinline__ void row64_inverse(typename A::T (&x)[16], uint64_t *lds, const uint32_t t, const Row64Args &a,
                                               const ModParams64 &m)
 {
-    reg_ntt64<4, false>(x, a.iroots, m);
+    reg_ntt64<A, 4, false>(x, a.iroots, m);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) lds[Q2(t * 16 + j)] = x[j];
+    for (int j = 0; j < 16; ++j) lds[Q2(t * 16 + j)] = A::bits(x[j]);
     __syncthreads();
     const uint32_t b = t >> 4, i = t & 15;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = lds[Q2(b * 256 + k * 16 + i)];
+    for (int k = 0; k < 16; ++k) x[k] = A::raw(lds[Q2(b * 256 + k * 16 + i)]);
     __syncthreads();
 #pragma unroll
-    for (int k = 1; k < 16; ++k) x[k] = M64::mulw(x[k], a.itwB[k * 16 + i], m);
-    reg_ntt64<4, false>(x, a.iroots, m);
+    for (int k = 1; k < 16; ++k) x[k] = A::mulw(x[k], A::raw(a.itwB[k * 16 + i]), m);
+    reg_ntt64<A, 4, false>(x, a.iroots, m);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) lds[Q1(b * 256 + j * 16 + i)] = x[j];
+    for (int j = 0; j < 16; ++j) lds[Q1(b * 256 + j * 16 + i)] = A::bits(x[j]);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = lds[Q1(k * 256 + t)];
+    for (int k = 0; k < 16; ++k) x[k] = A::raw(lds[Q1(k * 256 + t)]);
     __syncthreads();
 #pragma unroll
-    for (int k = 1; k < 16; ++k) x[k] = M64::mulw(x[k], a.itwA[k * 256 + t], m);
-    reg_ntt64<4, false>(x, a.iroots, m);
+    for (int k = 1; k < 16; ++k) x[k] = A::mulw(x[k], A::raw(a.itwA[k * 256 + t]), m);
+    reg_ntt64<A, 4, false>(x, a.iroots, m);
 }
 
 // Fused multiply of one 4096-point row: forward a, forward b, pointwise, inverse (in place on a's row).
+template <class A>
 __global__ void __launch_bounds__(256) row64_mul_kernel(const Row64Args a, const ModParams64 m)
 {
+    using T = typename A::T;
     __shared__ uint64_t lds[kRow64Words];
     const uint32_t t = threadIdx.x;
     const size_t row = (size_t)blockIdx.x * kRowLen;
     const uint64_t *__restrict__ pa = a.a + row;
     const uint64_t *__restrict__ pb = a.b + row;
-    uint64_t xa[16], xb[16];
+    T xa[16], xb[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) xa[j] = pa[t + 256 * j];
+    for (int j = 0; j < 16; ++j) xa[j] = A::raw(pa[t + 256 * j]);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) xb[j] = pb[t + 256 * j];
-    row64_forward(xa, lds, t, a, m);
-    row64_forward(xb, lds, t, a, m);
+    for (int j = 0; j < 16; ++j) xb[j] = A::raw(pb[t + 256 * j]);
+    row64_forward<A>(xa, lds, t, a, m);
+    row64_forward<A>(xb, lds, t, a, m);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) xa[k] = M64::mulw(xa[k], xb[k], m);      // REDC(a*b); R^-1 folded into the scale
-    row64_inverse(xa, lds, t, a, m);
+    for (int k = 0; k < 16; ++k) xa[k] = A::mulw(xa[k], xb[k], m);      // M64: REDC(a*b); R^-1 folded into the scale
+    row64_inverse<A>(xa, lds, t, a, m);
     uint64_t *__restrict__ po = a.out + row;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) po[t + 256 * j] = xa[j];
+    for (int j = 0; j < 16; ++j) po[t + 256 * j] = A::bits(xa[j]);
 }
 
 void launch_row64_mul(const Row64Args &a, const ModParams64 &mp, unsigned rows, hipStream_t s)
 {
-    hipLaunchKernelGGL(row64_mul_kernel, dim3(rows), dim3(256), 0, s, a, mp);
+    if (mp.fp) hipLaunchKernelGGL(row64_mul_kernel<F64>, dim3(rows), dim3(256), 0, s, a, mp);
+    else hipLaunchKernelGGL(row64_mul_kernel<M64>, dim3(rows), dim3(256), 0, s, a, mp);
 }
 
 void launch_lds64(const Lds64Args &a, const ModParams64 &mp, unsigned blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL(lds64_kernel, dim3(blocks), dim3(256), 0, s, a, mp);
+    if (mp.fp) hipLaunchKernelGGL(lds64_kernel<F64>, dim3(blocks), dim3(256), 0, s, a, mp);
+    else hipLaunchKernelGGL(lds64_kernel<M64>, dim3(blocks), dim3(256), 0, s, a, mp);
 }
 
 }  // namespace ntt

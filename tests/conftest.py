@@ -50,3 +50,15 @@ def ref_polymul_vectors():
 @pytest.fixture(scope="session")
 def crt_vectors():
     return np.load(os.path.join(GOLDEN, "crt_vectors.npz"))
+
+
+@pytest.fixture(params=["f64", "int"])
+def lanes64(request, monkeypatch):
+    """Both arithmetic policies of the 64-bit path (kernels_u64.hip): primes below 2^51 run as exact integers
+    in FP64 lanes by default; NTT_AMD_PLAN64_INT=1 (read when a plan is created) keeps them on the Montgomery
+    lanes.  Primes of 51 bits and more take the Montgomery lanes either way."""
+    if request.param == "int":
+        monkeypatch.setenv("NTT_AMD_PLAN64_INT", "1")
+    else:
+        monkeypatch.delenv("NTT_AMD_PLAN64_INT", raising=False)
+    return request.param

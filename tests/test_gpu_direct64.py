@@ -20,6 +20,7 @@ P51 = 1337006139375617            # reference case 5 (main-openmp.cc:636), 2-adi
 P62 = 4611685941117976577         # largest prime k * 2^32 + 1 below 2^62
 P50 = 1125899437080577            # largest prime k * 2^24 + 1 below 2^50
 P33 = 8588886017                  # largest prime k * 2^20 + 1 below 2^33
+P51B = 2251799696244737           # largest prime k * 2^24 + 1 below 2^51: the widest the FP64 lanes take
 
 
 @pytest.fixture(scope="module")
@@ -33,6 +34,11 @@ def ctx(nt):
     c = nt.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(autouse=True)
+def _both_policies(lanes64):
+    return lanes64
 
 
 def school(a, b, p):
@@ -76,6 +82,20 @@ def test_direct64_vs_crt_oracle(ctx, n):
     got = plan.multiply(a, b)[0]
     plan.close()
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n", [7, 4096, 50000, 65536])
+def test_direct64_top_of_fp64_range(ctx, n):
+    """p just below 2^51, where the rounding bounds of the FP64 multiplication are tightest (|x*w/p| up to
+    2^52): random and all-(p-1) operands against the CRT oracle (n * p^2 < product of its primes up to 2^17)."""
+    rng = np.random.default_rng(51 + n)
+    plan = ctx.plan64(P51B, n)
+    for a, b in ((rng.integers(0, P51B, size=n, dtype=np.uint64), rng.integers(0, P51B, size=n, dtype=np.uint64)),
+                 (np.full(n, P51B - 1, dtype=np.uint64), np.full(n, P51B - 1, dtype=np.uint64)),
+                 (np.full(n, P51B - 1, dtype=np.uint64), np.ones(n, dtype=np.uint64))):
+        want, _ = orc.poly_multiply_crt(a, b, P51B, threads=8)
+        assert np.array_equal(plan.multiply(a, b)[0], want)
+    plan.close()
 
 
 def test_direct64_matches_crt_path_on_gpu(ctx):

@@ -188,7 +188,7 @@ def fold(ab, n, p):
 
 
 @pytest.mark.parametrize("n", [2, 8, 256, 4096, 8192, 65536, 131072])
-def test_negacyclic64_vs_linear_crt_oracle(ctx, n):
+def test_negacyclic64_vs_linear_crt_oracle(ctx, n, lanes64):
     """Small block (L <= 4096), one column level, two levels; against the 4-prime CRT oracle's linear product."""
     rng = np.random.default_rng(n)
     a = rng.integers(0, P51, size=n, dtype=np.uint64)
@@ -202,7 +202,7 @@ def test_negacyclic64_vs_linear_crt_oracle(ctx, n):
     assert np.array_equal(got, fold(lin, n, P51))
 
 
-def test_negacyclic64_golden_and_schoolbook(ctx, crt_vectors):
+def test_negacyclic64_golden_and_schoolbook(ctx, crt_vectors, lanes64):
     v = crt_vectors                       # big-integer golden linear product, n = 256
     plan = ctx.negacyclic_plan64(int(v["p64"]), 256)
     assert np.array_equal(plan.multiply(v["a_256"], v["b_256"])[0], fold(v["ab_256"], 256, int(v["p64"])))
@@ -225,7 +225,7 @@ def test_negacyclic64_golden_and_schoolbook(ctx, crt_vectors):
         assert np.array_equal(got, np.array([x % P62 for x in c], dtype=np.uint64)), n
 
 
-def test_negacyclic64_ring_identity_and_batch(nt, ctx):
+def test_negacyclic64_ring_identity_and_batch(nt, ctx, lanes64):
     """62-bit prime at n = 2^15, a batch on device arrays with a padded row stride: x^k * a rotates with a sign."""
     import torch
     n, B, p = 32768, 5, P62
@@ -255,7 +255,7 @@ def test_negacyclic64_ring_identity_and_batch(nt, ctx):
         ctx.negacyclic_plan64(p, 1000)
 
 
-def test_randomised_shapes_all_rings(nt, ctx):
+def test_randomised_shapes_all_rings(nt, ctx, lanes64):
     """Seeded sweep over ring, lane width, prime, size and batch: every combination against the linear
     product of the oracle (folded for x^n + 1)."""
     rng = np.random.default_rng(2025)
