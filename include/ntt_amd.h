@@ -142,7 +142,10 @@ int ntt_crt_multiply_batched(ntt_ctx *ctx, const uint64_t *a, const uint64_t *b,
  * Replaces the single-modulus branch of main-openmp.cc:678-692 (`montgomery m(R = 2^60, p_)`,
  * :650-651: toMontgomery, NTT_iterative x2, pointwise ModMul, inverse, fromMontgomery), which the
  * reference only takes for p_ < 2^50; with 64-bit lanes it also serves the 51-bit modulus of the
- * reference's fifth case, i.e. the caller of ntt_crt_multiply, for a prime of this shape. */
+ * reference's fifth case, i.e. the caller of ntt_crt_multiply, for a prime of this shape.
+ * A prime below 2^51 runs as exact integers in FP64 lanes (same results bit for bit, about 1.5x faster;
+ * environment NTT_AMD_PLAN64_INT=1 at plan creation keeps the Montgomery lanes).  Operand values must be
+ * < p64 (the reference's data are); values >= p64 are outside the contract of this entry point. */
 typedef struct ntt_plan64 ntt_plan64;
 int ntt_plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, ntt_plan64 **out);
 int ntt_plan64_destroy(ntt_plan64 *plan);
