@@ -157,6 +157,22 @@ def test_multi_level_columns(ctx):
         plan.close()
 
 
+def test_largest_product_of_the_headline_prime(ctx):
+    """n = 2^22: L = 2^23 is the whole 2-adicity of 998244353 (three column levels + rows); the reference's
+    own arrays stop at 300000 entries (main-montgomery.cc:297), far below.  Checked against the oracle's
+    Barrett body (power-of-two padding, main-barrett.cc): the Montgomery body pads to a power of FOUR
+    (main-montgomery.cc:317-321), would need 2^24 | p - 1 here and is not a valid transform at this size."""
+    rng = np.random.default_rng(22)
+    n, p = 1 << 22, 998244353
+    a, b = rand_poly(rng, n, p), rand_poly(rng, n, p)
+    a[-1] = b[-1] = p - 1
+    plan = ctx.plan(p, n, 1, 0)
+    got = plan.multiply(a.reshape(1, n), b.reshape(1, n))[0]
+    plan.close()
+    assert np.array_equal(got, orc.poly_multiply(a, b, p, kind="barrett"))
+    assert got[-1] == 1                                   # (p - 1)^2
+
+
 def test_edge_values(ctx):
     p = 998244353
     for n in (4, 4096, 8192):
