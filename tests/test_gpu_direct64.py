@@ -138,6 +138,34 @@ def test_direct64_evaluation_identity(ctx, p, n):
         assert horner(a, x, p) * horner(b, x, p) % p == horner(ab, x, p), x
 
 
+@pytest.mark.parametrize("p,n", [(P51, (1 << 19) + 3), (P51, 1 << 22), (P62, 1 << 21), (P51B, 1 << 20)])
+def test_direct64_large_sizes(ctx, p, n):
+    """Two and three column levels in front of the rows (L = 2^21 ... 2^23; the plan limit is n = 2^23):
+    beyond the CRT oracle's exactness bound, so checked through A(x) * B(x) = AB(x) at x = 1, -1 (sums)
+    and one Horner evaluation, plus the two end coefficients."""
+    rng = np.random.default_rng(n % 1000)
+    a = rng.integers(0, p, size=n, dtype=np.uint64)
+    b = rng.integers(0, p, size=n, dtype=np.uint64)
+    a[-1] = b[-1] = p - 1
+    plan = ctx.plan64(p, n)
+    ab = plan.multiply(a, b)[0]
+    plan.close()
+    assert ab.max() < p
+    assert int(ab[0]) == int(a[0]) * int(b[0]) % p and int(ab[-1]) == 1
+
+    def at1(c):
+        return sum(int(v) for v in np.add.reduceat(c >> np.uint64(32), np.arange(0, c.size, 1 << 20)).tolist()) * (1 << 32) \
+            + sum(int(v) for v in np.add.reduceat(c & np.uint64(0xFFFFFFFF), np.arange(0, c.size, 1 << 20)).tolist())
+
+    def atm1(c):
+        return at1(c[0::2]) - at1(c[1::2])
+    assert at1(a) * at1(b) % p == at1(ab) % p
+    assert atm1(a) * atm1(b) % p == atm1(ab) % p
+    if n <= (1 << 20):
+        x = 0x123456789ABCDEF % p
+        assert horner(a, x, p) * horner(b, x, p) % p == horner(ab, x, p)
+
+
 def test_direct64_edge_values(ctx):
     n = 4096
     plan = ctx.plan64(P51, n)

@@ -157,6 +157,21 @@ def test_multi_level_columns(ctx):
         plan.close()
 
 
+def test_multi_level_columns_batched(ctx):
+    """Two column levels with a batch, a ragged n, an odd output stride and both reductions."""
+    rng = np.random.default_rng(6)
+    n, p, B = 300001, 469762049, 3
+    stride = 2 * n + 5
+    a, b = rand_poly(rng, n, p, B), rand_poly(rng, n, p, B)
+    for kind in (0, 1):
+        plan = ctx.plan(p, n, B, kind)
+        got = plan.multiply(a, b, out=np.full((B, stride), 7, dtype=np.uint32), out_stride=stride)
+        plan.close()
+        for r in range(B):
+            assert np.array_equal(got[r, :2 * n - 1], orc.poly_multiply(a[r], b[r], p, kind="barrett")), (kind, r)
+        assert np.all(got[:, 2 * n - 1:] == 7)
+
+
 def test_largest_product_of_the_headline_prime(ctx):
     """n = 2^22: L = 2^23 is the whole 2-adicity of 998244353 (three column levels + rows); the reference's
     own arrays stop at 300000 entries (main-montgomery.cc:297), far below.  Checked against the oracle's
