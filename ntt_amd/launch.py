@@ -123,20 +123,32 @@ def main(argv=None):
                 ctx.synchronize()
                 return m
 
-        if on_gpu:
-            torch.cuda.synchronize()
-        total_ms = 0.0
-        for _ in range(args.epochs):
-            group.barrier()
-            t0 = time.perf_counter()                             # main-mpi.cc:708
+            if world == 1:                                       # all four primes and the merge on this rank
+                ab = torch.zeros(2 * n - 1, dtype=torch.int64, device=device)
+                crt_out = ab if on_gpu else ab.numpy().view(np.uint64)
+
+        def epoch():
+            nonlocal ab
             if single:
                 if rank == 0:
                     plan.multiply(a_op, b_op, out=out_op)
                     ctx.synchronize()
+            elif world == 1:
+                ctx.crt_multiply(a_op, b_op, p, out=crt_out)
+                ctx.synchronize()
             else:
                 ab = shard.crt_multiply_sharded(group, residue_fn, merge_fn, n, device=device)
                 if on_gpu:
                     torch.cuda.synchronize()
+
+        if on_gpu:
+            torch.cuda.synchronize()
+        epoch()                                                  # untimed: code objects, tables, workspaces
+        total_ms = 0.0
+        for _ in range(args.epochs):
+            group.barrier()
+            t0 = time.perf_counter()                             # main-mpi.cc:708
+            epoch()
             total_ms += 1e3 * (time.perf_counter() - t0)         # main-mpi.cc:799-801
         if plan is not None:
             plan.close()
@@ -145,10 +157,14 @@ def main(argv=None):
             res = ab.cpu().numpy()
             res = res.view(np.uint32) if res.dtype == np.int32 else res.view(np.uint64)
             sys.stdout.flush()
-            if args.bin:
-                ok = ntt_amd.check_case_bin(args.data, cid, res if p >= (1 << 32) else res.astype(np.uint32))
-            else:
-                ok = ntt_amd.check_case(args.data, cid, res.astype(np.uint64))
+            try:
+                if args.bin:
+                    ok = ntt_amd.check_case_bin(args.data, cid, res if p >= (1 << 32) else res.astype(np.uint32))
+                else:
+                    ok = ntt_amd.check_case(args.data, cid, res.astype(np.uint64))
+            except ntt_amd.NttError as e:                        # no (readable) expected output: not a pass
+                print(f"case {cid} not checked: {e}", file=sys.stderr, flush=True)
+                ok = False
             failures += 0 if ok else 1
             print(f"average latency for n = {n} p = {p} : {total_ms / max(args.epochs, 1):g} (us)", flush=True)
             if args.bin:
