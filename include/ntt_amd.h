@@ -31,7 +31,8 @@ typedef enum {
     NTT_ERR_HIP = 3,          /* HIP runtime failure; ntt_last_error() holds hipGetErrorString */
     NTT_ERR_NOMEM = 4,
     NTT_ERR_IO = 5,           /* fixture file missing / malformed */
-    NTT_ERR_MISMATCH = 6      /* ntt_check_case: result differs from the .out file */
+    NTT_ERR_MISMATCH = 6,     /* ntt_check_case: result differs from the .out file */
+    NTT_ERR_INTERNAL = 7      /* a C++ exception other than bad_alloc stopped at the boundary (none crosses it) */
 } ntt_status;
 
 /* Modular-multiplication flavour of a plan.  Both give canonical residues in [0,p) and hence

@@ -30,7 +30,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NTT_AMD_LIB selects another build of the same library (A/B experiments under ntt_amd/variants/)
 _LIB_PATH = os.environ.get("NTT_AMD_LIB") or os.path.join(_HERE, "libntt_amd.so")
 
-OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM, ERR_IO, ERR_MISMATCH = range(7)
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM, ERR_IO, ERR_MISMATCH, ERR_INTERNAL = range(8)
 MONTGOMERY, BARRETT = 0, 1
 
 EXPORTED_SYMBOLS = (

@@ -68,14 +68,15 @@ static int crt_plans(ntt_ctx *ctx, int n, int batch);
 
 extern "C" int ntt_crt_multiply(ntt_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *ab, int n,
                                 uint64_t p64)
-{
+try {
     return ntt_crt_multiply_batched(ctx, a, b, ab, n, p64, 1);
 }
+NTT_CATCH_STATUS
 
 // batch products: a, b [batch][n], ab [batch][2n-1] (contiguous rows); batch == 1 is ntt_crt_multiply
 extern "C" int ntt_crt_multiply_batched(ntt_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *ab, int n,
                                         uint64_t p64, int batch)
-{
+try {
     if (!ctx || !a || !b || !ab) return fail(NTT_ERR_INVALID, "ntt_crt_multiply: null argument");
     if (n <= 0 || batch <= 0) return fail(NTT_ERR_INVALID, "ntt_crt_multiply: n and batch must be positive");
     if ((uint64_t)batch * (uint64_t)n > (1ull << 28)) return fail(NTT_ERR_UNSUPPORTED, "ntt_crt_multiply_batched: batch * n above 2^28");
@@ -157,6 +158,7 @@ extern "C" int ntt_crt_multiply_batched(ntt_ctx *ctx, const uint64_t *a, const u
     }
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 // ---- the two halves of the CRT path as separate entry points (prime-per-GPU sharding) --------------
 static int crt_check(ntt_ctx *ctx, int n, uint64_t p64, bool need_p64)
@@ -184,15 +186,16 @@ static int crt_plans(ntt_ctx *ctx, int n, int batch)
 }
 
 extern "C" int ntt_crt_prime(int index, uint32_t *p)
-{
+try {
     if (index < 0 || index >= 4 || !p) return fail(NTT_ERR_INVALID, "ntt_crt_prime: index must be 0..3");
     *p = kCrtMods[index];
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 extern "C" int ntt_crt_residue_multiply(ntt_ctx *ctx, const uint64_t *a, const uint64_t *b, uint32_t *res,
                                         int n, int prime_index)
-{
+try {
     int rc = crt_check(ctx, n, 0, false);
     if (rc) return rc;
     if (!a || !b || !res || prime_index < 0 || prime_index >= 4)
@@ -234,10 +237,11 @@ extern "C" int ntt_crt_residue_multiply(ntt_ctx *ctx, const uint64_t *a, const u
     }
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 extern "C" int ntt_crt_merge(ntt_ctx *ctx, const uint32_t *r0, const uint32_t *r1, const uint32_t *r2,
                              const uint32_t *r3, uint64_t *out, size_t count, uint64_t p64)
-{
+try {
     int rc = crt_check(ctx, 1, p64, true);
     if (rc) return rc;
     if (!r0 || !r1 || !r2 || !r3 || !out || count == 0) return fail(NTT_ERR_INVALID, "ntt_crt_merge: bad argument");
@@ -279,13 +283,14 @@ extern "C" int ntt_crt_merge(ntt_ctx *ctx, const uint32_t *r0, const uint32_t *r
     }
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 // ---- the reference's entry point ---------------------------------------------------------------------
 static ntt_ctx *g_ctx = nullptr;
 static std::mutex g_mu;
 
 extern "C" void poly_multiply(int *a, int *b, int *ab, int n, int p)
-{
+try {
     auto die = [](const char *what) {
         std::fprintf(stderr, "ntt_amd: poly_multiply failed: %s: %s\n", what, ntt_last_error());
         std::abort();
@@ -314,4 +319,9 @@ extern "C" void poly_multiply(int *a, int *b, int *ab, int n, int p)
     if (ntt_poly_multiply_batched(pl, reinterpret_cast<const uint32_t *>(a), reinterpret_cast<const uint32_t *>(b),
                                   reinterpret_cast<uint32_t *>(ab), (size_t)2 * n - 1, 1) != NTT_OK)
         die("ntt_poly_multiply_batched");
+}
+catch (...) {                      // the signature cannot report: same treatment as any other failure
+    (void)ntt::exception_status();
+    std::fprintf(stderr, "ntt_amd: poly_multiply failed: %s\n", ntt_last_error());
+    std::abort();
 }

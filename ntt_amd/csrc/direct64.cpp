@@ -300,15 +300,17 @@ int multiply_device(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64
 static int plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, bool negacyclic, ntt_plan64 **out);
 
 extern "C" int ntt_plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, ntt_plan64 **out)
-{
+try {
     return plan64_create(ctx, p64, n, batch, false, out);
 }
+NTT_CATCH_STATUS
 
 extern "C" int ntt_negacyclic_plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, ntt_plan64 **out)
-{
+try {
     if (n < 2 || (n & (n - 1)) != 0) return fail(NTT_ERR_INVALID, "ntt_negacyclic_plan64_create: n must be a power of two >= 2");
     return plan64_create(ctx, p64, n, batch, true, out);
 }
+NTT_CATCH_STATUS
 
 static int plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, bool negacyclic, ntt_plan64 **out)
 {
@@ -364,7 +366,7 @@ static int plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, bool nega
 }
 
 extern "C" int ntt_plan64_destroy(ntt_plan64 *pl)
-{
+try {
     if (!pl) return NTT_OK;
     (void)hipSetDevice(pl->ctx->device);
     (void)hipStreamSynchronize(pl->ctx->stream);
@@ -374,28 +376,32 @@ extern "C" int ntt_plan64_destroy(ntt_plan64 *pl)
     delete pl;
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 extern "C" int ntt_plan64_length(const ntt_plan64 *pl, uint32_t *L)
-{
+try {
     if (!pl || !L) return fail(NTT_ERR_INVALID, "ntt_plan64_length: null argument");
     *L = pl->L;
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 static int multiply64_entry(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64_t *ab, size_t ab_stride,
                             int batch, bool negacyclic);
 
 extern "C" int ntt_poly_multiply64_batched(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64_t *ab,
                                            size_t ab_stride, int batch)
-{
+try {
     return multiply64_entry(pl, a, b, ab, ab_stride, batch, false);
 }
+NTT_CATCH_STATUS
 
 extern "C" int ntt_negacyclic_multiply64_batched(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64_t *c,
                                                  size_t c_stride, int batch)
-{
+try {
     return multiply64_entry(pl, a, b, c, c_stride, batch, true);
 }
+NTT_CATCH_STATUS
 
 static int multiply64_entry(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64_t *ab, size_t ab_stride,
                             int batch, bool negacyclic)

@@ -4,6 +4,8 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <exception>
+#include <new>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,6 +27,25 @@ int fail(int code, const std::string &msg)
 {
     g_err = msg;
     return code;
+}
+
+// The C ABI lets no exception out (NTT_CATCH_STATUS closes every entry point): called inside a catch block,
+// turns the exception in flight into a status code and a message.
+int exception_status() noexcept
+{
+    try {
+        try {
+            throw;
+        } catch (const std::bad_alloc &) {
+            return fail(NTT_ERR_NOMEM, "out of host memory");
+        } catch (const std::exception &e) {
+            return fail(NTT_ERR_INTERNAL, std::string("unexpected exception: ") + e.what());
+        } catch (...) {
+            return fail(NTT_ERR_INTERNAL, "unexpected exception");
+        }
+    } catch (...) {               // not even the message could be stored
+        return NTT_ERR_NOMEM;
+    }
 }
 const char *last_error_cstr() { return g_err.c_str(); }
 
@@ -610,7 +631,7 @@ extern "C" {
 const char *ntt_last_error(void) { return ntt::last_error_cstr(); }
 
 int ntt_ctx_create(const int *device_ids, int ndev, ntt_ctx **out_ctx)
-{
+try {
     if (!out_ctx) return fail(NTT_ERR_INVALID, "ntt_ctx_create: out_ctx is null");
     *out_ctx = nullptr;
     if (ndev != 1) return fail(NTT_ERR_UNSUPPORTED, "ntt_ctx_create: one process drives one GPU (ndev must be 1)");
@@ -645,27 +666,30 @@ int ntt_ctx_create(const int *device_ids, int ndev, ntt_ctx **out_ctx)
     *out_ctx = cx;
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 int ntt_ctx_set_stream(ntt_ctx *ctx, void *hip_stream)
-{
+try {
     if (!ctx) return fail(NTT_ERR_INVALID, "null context");
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     ctx->cur = ctx->stream;
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 void *ntt_ctx_stream(ntt_ctx *ctx) { return ctx ? static_cast<void *>(ctx->stream) : nullptr; }
 
 int ntt_ctx_synchronize(ntt_ctx *ctx)
-{
+try {
     if (!ctx) return fail(NTT_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 int ntt_ctx_enable_kernel_timing(ntt_ctx *ctx, int enable)
-{
+try {
     if (!ctx) return fail(NTT_ERR_INVALID, "null context");
     std::lock_guard<std::mutex> lk(ctx->mu);
     int rc = ctx->fold();
@@ -673,18 +697,20 @@ int ntt_ctx_enable_kernel_timing(ntt_ctx *ctx, int enable)
     for (int i = 0; i < K_COUNT; ++i) { ctx->acc_ms[i] = 0; ctx->acc_n[i] = 0; }
     return rc;
 }
+NTT_CATCH_STATUS
 
 int ntt_ctx_kernel_timing_select(ntt_ctx *ctx, int index)
-{
+try {
     if (!ctx || index < -1 || index >= K_COUNT) return fail(NTT_ERR_INVALID, "ntt_ctx_kernel_timing_select: bad index");
     std::lock_guard<std::mutex> lk(ctx->mu);
     int rc = ctx->fold();
     ctx->timing_only = index;
     return rc;
 }
+NTT_CATCH_STATUS
 
 int ntt_ctx_kernel_time(ntt_ctx *ctx, int index, const char **name, double *total_ms, long *launches)
-{
+try {
     if (!ctx || index < 0 || index >= K_COUNT) return fail(NTT_ERR_INVALID, "ntt_ctx_kernel_time: bad index");
     std::lock_guard<std::mutex> lk(ctx->mu);
     int rc = ctx->fold();
@@ -694,9 +720,10 @@ int ntt_ctx_kernel_time(ntt_ctx *ctx, int index, const char **name, double *tota
     if (launches) *launches = ctx->acc_n[index];
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 int ntt_plan_destroy(ntt_plan *pl)
-{
+try {
     if (!pl) return NTT_OK;
     (void)hipSetDevice(pl->ctx->device);
     (void)hipStreamSynchronize(pl->ctx->stream);
@@ -706,9 +733,10 @@ int ntt_plan_destroy(ntt_plan *pl)
     delete pl;
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 int ntt_ctx_destroy(ntt_ctx *ctx)
-{
+try {
     if (!ctx) return NTT_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -730,19 +758,22 @@ int ntt_ctx_destroy(ntt_ctx *ctx)
     delete ctx;
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind, bool negacyclic, ntt_plan **out_plan);
 
 int ntt_plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind, ntt_plan **out_plan)
-{
+try {
     return plan_create(ctx, p, n, batch, modmul_kind, false, out_plan);
 }
+NTT_CATCH_STATUS
 
 int ntt_negacyclic_plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind, ntt_plan **out_plan)
-{
+try {
     if (n < 2 || (n & (n - 1)) != 0) return fail(NTT_ERR_INVALID, "ntt_negacyclic_plan_create: n must be a power of two >= 2");
     return plan_create(ctx, p, n, batch, modmul_kind, true, out_plan);
 }
+NTT_CATCH_STATUS
 
 static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind, bool negacyclic, ntt_plan **out_plan)
 {
@@ -835,15 +866,17 @@ static int multiply_entry(ntt_plan *pl, const uint32_t *a, const uint32_t *b, ui
 
 int ntt_poly_multiply_batched(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
                               size_t ab_stride, int batch)
-{
+try {
     return multiply_entry(pl, a, b, ab, ab_stride, batch, false);
 }
+NTT_CATCH_STATUS
 
 int ntt_negacyclic_multiply_batched(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *c,
                                     size_t c_stride, int batch)
-{
+try {
     return multiply_entry(pl, a, b, c, c_stride, batch, true);
 }
+NTT_CATCH_STATUS
 
 static int multiply_entry(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab, size_t ab_stride,
                           int batch, bool negacyclic)
@@ -922,8 +955,16 @@ static int transform_entry(ntt_plan *pl, uint32_t *data, int batch, bool inverse
     return NTT_OK;
 }
 
-int ntt_forward(ntt_plan *plan, uint32_t *data, int batch) { return transform_entry(plan, data, batch, false); }
-int ntt_inverse(ntt_plan *plan, uint32_t *data, int batch) { return transform_entry(plan, data, batch, true); }
+int ntt_forward(ntt_plan *plan, uint32_t *data, int batch)
+try {
+    return transform_entry(plan, data, batch, false);
+}
+NTT_CATCH_STATUS
+int ntt_inverse(ntt_plan *plan, uint32_t *data, int batch)
+try {
+    return transform_entry(plan, data, batch, true);
+}
+NTT_CATCH_STATUS
 
 }  // extern "C"
 
@@ -986,17 +1027,18 @@ static int build_dist_tables(ntt_dist_plan *dp, uint32_t p, uint32_t g)
 extern "C" {
 
 int ntt_dist_plan_destroy(ntt_dist_plan *dp)
-{
+try {
     if (!dp) return NTT_OK;
     if (dp->local) ntt_plan_destroy(dp->local);
     if (dp->colp) ntt_plan_destroy(dp->colp);
     delete dp;
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 int ntt_dist_plan_create(ntt_ctx *ctx, uint32_t p, int lgL, int world, int rank, int modmul_kind,
                          ntt_dist_plan **out)
-{
+try {
     if (!ctx || !out) return fail(NTT_ERR_INVALID, "ntt_dist_plan_create: null argument");
     *out = nullptr;
     if (world < 2 || world > 64 || (world & (world - 1)) || rank < 0 || rank >= world)
@@ -1041,9 +1083,10 @@ int ntt_dist_plan_create(ntt_ctx *ctx, uint32_t p, int lgL, int world, int rank,
     *out = dp.release();
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 int ntt_dist_colpass(ntt_dist_plan *dp, uint32_t *data, int inverse)
-{
+try {
     if (!dp || !data) return fail(NTT_ERR_INVALID, "ntt_dist_colpass: null argument");
     ntt_ctx *cx = dp->ctx;
     std::lock_guard<std::mutex> lk(cx->mu);
@@ -1062,12 +1105,14 @@ int ntt_dist_colpass(ntt_dist_plan *dp, uint32_t *data, int inverse)
     HIP_TRY(hipGetLastError());
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 int ntt_dist_local(ntt_dist_plan *dp, uint32_t *row, int inverse)
-{
+try {
     if (!dp) return fail(NTT_ERR_INVALID, "ntt_dist_local: null argument");
     return inverse ? ntt_inverse(dp->local, row, 1) : ntt_forward(dp->local, row, 1);
 }
+NTT_CATCH_STATUS
 
 int ntt_dist_local_length(const ntt_dist_plan *dp) { return dp ? (int)dp->S : 0; }
 

@@ -22,6 +22,9 @@ extern const char *const kKernelNames[K_COUNT];
 
 void set_error(const std::string &msg);
 int fail(int code, const std::string &msg);
+int exception_status() noexcept;
+// function-try-block handler of every status-returning extern "C" entry point
+#define NTT_CATCH_STATUS catch (...) { return ntt::exception_status(); }
 
 struct DeviceBuffer {
     void *ptr = nullptr;

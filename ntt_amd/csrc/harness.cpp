@@ -53,7 +53,7 @@ std::string case_path(const char *dir, int id, const char *ext)
 }  // namespace
 
 extern "C" int ntt_read_case(const char *dir, int id, uint64_t *a, uint64_t *b, size_t cap, int *n, uint64_t *p)
-{
+try {
     if (!a || !b || !n || !p) return ntt::fail(NTT_ERR_INVALID, "ntt_read_case: null argument");
     const std::string path = case_path(dir, id, ".in");
     std::vector<char> buf;
@@ -71,9 +71,10 @@ extern "C" int ntt_read_case(const char *dir, int id, uint64_t *a, uint64_t *b, 
     *p = pp;
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 extern "C" int ntt_check_case(const char *dir, int id, const uint64_t *ab, int n)
-{
+try {
     if (!ab || n <= 0) return ntt::fail(NTT_ERR_INVALID, "ntt_check_case: bad argument");
     const std::string path = case_path(dir, id, ".out");
     std::vector<char> buf;
@@ -92,9 +93,10 @@ extern "C" int ntt_check_case(const char *dir, int id, const uint64_t *ab, int n
     std::fflush(stdout);
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 extern "C" int ntt_write_case(const char *dir, int id, const uint64_t *ab, int n)
-{
+try {
     if (!ab || n <= 0) return ntt::fail(NTT_ERR_INVALID, "ntt_write_case: bad argument");
     const std::string path = case_path(dir, id, ".out");
     FILE *f = std::fopen(path.c_str(), "wb");
@@ -110,6 +112,7 @@ extern "C" int ntt_write_case(const char *dir, int id, const uint64_t *ab, int n
     std::fclose(f);
     return ok ? NTT_OK : ntt::fail(NTT_ERR_IO, "ntt_write_case: short write to " + path);
 }
+NTT_CATCH_STATUS
 
 // ---- packed binary cases -----------------------------------------------------------
 // Parsing 2 MB of decimals per case costs more than the GPU multiply it feeds (fRead,
@@ -163,7 +166,7 @@ int write_packed(const std::string &path, uint32_t kind, uint32_t width, uint64_
 }  // namespace
 
 extern "C" int ntt_pack_case(const char *dir, int id)
-{
+try {
     std::vector<char> buf;
     const std::string in_path = case_path(dir, id, ".in");
     if (!slurp(in_path, buf)) return ntt::fail(NTT_ERR_IO, "ntt_pack_case: cannot read " + in_path);
@@ -187,10 +190,11 @@ extern "C" int ntt_pack_case(const char *dir, int id)
         if (!next_u64(buf, pos, ab[i])) return ntt::fail(NTT_ERR_IO, "ntt_pack_case: truncated " + out_path);
     return write_packed(case_path(dir, id, ".outb"), 2, width, n, p, ab.data(), ab.size(), nullptr, 0);
 }
+NTT_CATCH_STATUS
 
 extern "C" int ntt_read_case_bin(const char *dir, int id, void *a, void *b, size_t cap_bytes, int *n, uint64_t *p,
                                  int *width)
-{
+try {
     if (!a || !b || !n || !p || !width) return ntt::fail(NTT_ERR_INVALID, "ntt_read_case_bin: null argument");
     const std::string path = case_path(dir, id, ".inb");
     FILE *f = std::fopen(path.c_str(), "rb");
@@ -210,9 +214,10 @@ extern "C" int ntt_read_case_bin(const char *dir, int id, void *a, void *b, size
     *width = (int)h.width;
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 extern "C" int ntt_check_case_bin(const char *dir, int id, const void *ab, int n, int width)
-{
+try {
     if (!ab || n <= 0 || (width != 4 && width != 8)) return ntt::fail(NTT_ERR_INVALID, "ntt_check_case_bin: bad argument");
     const std::string path = case_path(dir, id, ".outb");
     FILE *f = std::fopen(path.c_str(), "rb");
@@ -238,9 +243,10 @@ extern "C" int ntt_check_case_bin(const char *dir, int id, const void *ab, int n
     std::fflush(stdout);
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 extern "C" int ntt_write_case_bin(const char *dir, int id, const void *ab, int n, uint64_t p, int width)
-{
+try {
     if (!ab || n <= 0 || (width != 4 && width != 8)) return ntt::fail(NTT_ERR_INVALID, "ntt_write_case_bin: bad argument");
     const std::string path = case_path(dir, id, ".outb");
     FILE *f = std::fopen(path.c_str(), "wb");
@@ -253,3 +259,4 @@ extern "C" int ntt_write_case_bin(const char *dir, int id, const void *ab, int n
     std::fclose(f);
     return ok ? NTT_OK : ntt::fail(NTT_ERR_IO, "ntt_write_case_bin: short write to " + path);
 }
+NTT_CATCH_STATUS

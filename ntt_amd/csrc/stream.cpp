@@ -150,7 +150,7 @@ static void parallel_copy(void *dst, const void *src, size_t bytes) { parallel_c
 }  // namespace ntt
 
 extern "C" int ntt_host_alloc(size_t bytes, void **ptr)
-{
+try {
     if (!ptr || bytes == 0) return fail(NTT_ERR_INVALID, "ntt_host_alloc: bad argument");
     *ptr = nullptr;
     hipError_t e = hipHostMalloc(ptr, bytes, hipHostMallocDefault);
@@ -160,17 +160,19 @@ extern "C" int ntt_host_alloc(size_t bytes, void **ptr)
     }
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 extern "C" int ntt_host_free(void *ptr)
-{
+try {
     if (!ptr) return NTT_OK;
     HIP_TRY(hipHostFree(ptr));
     return NTT_OK;
 }
+NTT_CATCH_STATUS
 
 extern "C" int ntt_poly_multiply_stream(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
                                         size_t ab_stride, size_t count)
-{
+try {
     if (!pl || !a || !b || !ab) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_stream: null argument");
     if (count == 0) return NTT_OK;
     if (pl->negacyclic) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_stream: not for negacyclic plans");
@@ -282,3 +284,4 @@ extern "C" int ntt_poly_multiply_stream(ntt_plan *pl, const uint32_t *a, const u
     HIP_TRY(hipStreamSynchronize(cx->stream));
     return NTT_OK;
 }
+NTT_CATCH_STATUS

@@ -235,3 +235,28 @@ def test_header_is_plain_c(tmp_path):
                     "-Wl,-rpath," + libdir, "-o", str(exe)], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stderr)
+
+
+def test_no_exception_crosses_the_c_abi(tmp_path):
+    """A C++ exception inside an entry point comes back as a status code (function-try-blocks, NTT_CATCH_STATUS):
+    under an address-space limit the 8 GiB operand vectors of a case header claiming n = 2^30 cannot be
+    allocated; std::bad_alloc must surface as NTT_ERR_NOMEM, not terminate the process."""
+    import subprocess
+    import sys
+    (tmp_path / "7.in").write_text("1073741824 7340033\n1 2 3\n")
+    code = r'''
+import resource, sys
+sys.path.insert(0, %r)
+import ntt_amd
+vm = [int(l.split()[1]) for l in open("/proc/self/status") if l.startswith("VmSize")][0] * 1024
+resource.setrlimit(resource.RLIMIT_AS, (vm + (1 << 30), vm + (1 << 30)))
+try:
+    ntt_amd.pack_case(%r, 7)
+except ntt_amd.NttError as e:
+    print("status", e.code)
+else:
+    print("no error")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip() == "status 4"          # NTT_ERR_NOMEM
