@@ -134,13 +134,18 @@ try {
         HIP_TRY(hipEventRecord(ctx->fork_ev, main_stream));
         HIP_TRY(hipStreamWaitEvent(ctx->lane[1], ctx->fork_ev, 0));
     }
-    for (int k = 0; k < 4 && !rc; ++k) {
-        ctx->stream = (two && (k & 1)) ? ctx->lane[1] : main_stream;     // the plan's launches follow ctx->stream
-        rc = multiply_device_any(w.plans[k], ra + k * N, rb + k * N, res + k * out_len, row_len, batch);
-        rows[k] = res + k * out_len;
+    {
+        struct Restore {                                   // whatever ends the loop, the context gets its stream back
+            ntt_ctx *c;
+            hipStream_t s;
+            ~Restore() { c->stream = s; c->cur = s; }
+        } restore{ctx, main_stream};
+        for (int k = 0; k < 4 && !rc; ++k) {
+            ctx->stream = (two && (k & 1)) ? ctx->lane[1] : main_stream;     // the plan's launches follow ctx->stream
+            rc = multiply_device_any(w.plans[k], ra + k * N, rb + k * N, res + k * out_len, row_len, batch);
+            rows[k] = res + k * out_len;
+        }
     }
-    ctx->stream = main_stream;
-    ctx->cur = main_stream;
     if (two) {
         HIP_TRY(hipEventRecord(ctx->lane_done[1], ctx->lane[1]));
         HIP_TRY(hipStreamWaitEvent(main_stream, ctx->lane_done[1], 0));

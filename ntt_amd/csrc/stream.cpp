@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -31,6 +32,15 @@ using namespace ntt;
 namespace ntt {
 
 constexpr int kRing = 3;
+
+// joins on scope exit, so that an early return or an exception never destroys a running thread
+struct JoinGuard {
+    std::thread t;
+    ~JoinGuard()
+    {
+        if (t.joinable()) t.join();
+    }
+};
 
 struct PinnedBuffer {
     void *ptr = nullptr;
@@ -76,26 +86,36 @@ void stream_release(ntt_ctx *ctx)
     ctx->stream_state = nullptr;
 }
 
+static int stream_state_create(ntt_ctx *ctx)
+{
+    auto *st = new StreamState();
+    ctx->stream_state = st;
+    HIP_TRY(hipStreamCreateWithFlags(&st->h2d, hipStreamNonBlocking));
+    // The runtime has four hardware queues per process (GPU_MAX_HW_QUEUES); a fifth stream shares
+    // one with another, and copy-out then serialises against copy-in or the kernels (measured: 28k
+    // vs 41k products/s).  The streamed multiply runs on one compute lane, so the context's second
+    // lane stream is free to carry the copy-out.
+    if (ctx->nlanes > 1 && ctx->lane[1]) {
+        st->d2h = ctx->lane[1];
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&st->d2h, hipStreamNonBlocking));
+        st->own_d2h = true;
+    }
+    for (int k = 0; k < kRing; ++k) {
+        HIP_TRY(hipEventCreateWithFlags(&st->in_done[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&st->mul_done[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&st->out_done[k], hipEventDisableTiming));
+    }
+    return NTT_OK;
+}
+
 static int stream_state(ntt_ctx *ctx, StreamState **out)
 {
     if (!ctx->stream_state) {
-        auto *st = new StreamState();
-        ctx->stream_state = st;
-        HIP_TRY(hipStreamCreateWithFlags(&st->h2d, hipStreamNonBlocking));
-        // The runtime has four hardware queues per process (GPU_MAX_HW_QUEUES); a fifth stream shares
-        // one with another, and copy-out then serialises against copy-in or the kernels (measured: 28k
-        // vs 41k products/s).  The streamed multiply runs on one compute lane, so the context's second
-        // lane stream is free to carry the copy-out.
-        if (ctx->nlanes > 1 && ctx->lane[1]) {
-            st->d2h = ctx->lane[1];
-        } else {
-            HIP_TRY(hipStreamCreateWithFlags(&st->d2h, hipStreamNonBlocking));
-            st->own_d2h = true;
-        }
-        for (int k = 0; k < kRing; ++k) {
-            HIP_TRY(hipEventCreateWithFlags(&st->in_done[k], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&st->mul_done[k], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&st->out_done[k], hipEventDisableTiming));
+        const int rc = stream_state_create(ctx);
+        if (rc) {                          // never leave a half-built ring behind for the next call
+            stream_release(ctx);
+            return rc;
         }
     }
     *out = ctx->stream_state;
@@ -141,8 +161,14 @@ static void parallel_copy2d(void *dst, size_t dpitch, const void *src, size_t sp
         return;
     }
     std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+    th.reserve(nt - 1);
+    unsigned started = 1;                  // share 0 is this thread's
+    try {
+        for (; started < nt; ++started) th.emplace_back(work, started);
+    } catch (...) {                        // no more threads to be had: the remaining shares run here
+    }
     work(0);
+    for (unsigned t = started; t < nt; ++t) work(t);
     for (auto &x : th) x.join();
 }
 static void parallel_copy(void *dst, const void *src, size_t bytes) { parallel_copy2d(dst, bytes, src, bytes, bytes, 1); }
@@ -244,44 +270,71 @@ try {
     // The copy-in of slice s + 1 is issued BEFORE the multiply and copy-out of slice s: measured
     // (rocprofv3 copy trace, profiles/), a device-to-host copy call can hold the calling thread until the
     // copy has run, and a copy-in issued after it starts only then.
-    if ((rc = issue_in(0))) return rc;
-    for (size_t s = 0; s < slices; ++s) {
-        const int k = (int)(s % kRing);
-        const size_t cnt = cnt_of(s);
-        // pageable memory: the result of slice s - kRing leaves its bounce buffer on a helper thread
-        // while this thread stages the next copy-in
-        int frc = NTT_OK;
-        std::thread fin;
-        if (s >= (size_t)kRing && !pin_o) fin = std::thread([&, s] { frc = finalize(s - kRing); });
-        if (s + 1 < slices) rc = issue_in(s + 1);
-        if (fin.joinable()) fin.join();                                        // hout[k] is free again
-        if (rc) return rc;
-        if (frc) return frc;
-        // multiply on the context's stream once the slice has landed and the slot's previous result
-        // has left
-        HIP_TRY(hipStreamWaitEvent(cx->stream, st->in_done[k], 0));
-        if (s >= (size_t)kRing) HIP_TRY(hipStreamWaitEvent(cx->stream, st->out_done[k], 0));
-        rc = multiply_device_any(pl, static_cast<const uint32_t *>(st->da[k].ptr),
-                                 static_cast<const uint32_t *>(st->db[k].ptr),
-                                 static_cast<uint32_t *>(st->dout[k].ptr), out_len, (int)cnt);
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(st->mul_done[k], cx->stream));
-        HIP_TRY(hipStreamWaitEvent(st->d2h, st->mul_done[k], 0));
-        if (pin_o && ab_stride == out_len) {
-            HIP_TRY(hipMemcpyAsync(ab + s * S * ab_stride, st->dout[k].ptr, cnt * out_len * 4, hipMemcpyDeviceToHost, st->d2h));
-        } else if (pin_o) {
-            HIP_TRY(hipMemcpy2DAsync(ab + s * S * ab_stride, ab_stride * 4, st->dout[k].ptr, out_len * 4, out_len * 4,
-                                     cnt, hipMemcpyDeviceToHost, st->d2h));
-        } else {
-            HIP_TRY(hipMemcpyAsync(st->hout[k].ptr, st->dout[k].ptr, cnt * out_len * 4, hipMemcpyDeviceToHost, st->d2h));
+    auto run = [&]() -> int {
+        int rc;
+        if ((rc = issue_in(0))) return rc;
+        for (size_t s = 0; s < slices; ++s) {
+            const int k = (int)(s % kRing);
+            const size_t cnt = cnt_of(s);
+            // pageable memory: the result of slice s - kRing leaves its bounce buffer on a helper thread
+            // while this thread stages the next copy-in
+            int frc = NTT_OK;
+            {
+                JoinGuard fin;
+                if (s >= (size_t)kRing && !pin_o) {
+                    try {
+                        fin.t = std::thread([&, s] { frc = finalize(s - kRing); });
+                    } catch (const std::system_error &) {                           // no thread: do it here
+                        frc = finalize(s - kRing);
+                    }
+                }
+                if (s + 1 < slices) rc = issue_in(s + 1);
+            }                                                                      // joined: hout[k] is free again
+            if (rc) return rc;
+            if (frc) return frc;
+            // multiply on the context's stream once the slice has landed and the slot's previous result
+            // has left
+            HIP_TRY(hipStreamWaitEvent(cx->stream, st->in_done[k], 0));
+            if (s >= (size_t)kRing) HIP_TRY(hipStreamWaitEvent(cx->stream, st->out_done[k], 0));
+            rc = multiply_device_any(pl, static_cast<const uint32_t *>(st->da[k].ptr),
+                                     static_cast<const uint32_t *>(st->db[k].ptr),
+                                     static_cast<uint32_t *>(st->dout[k].ptr), out_len, (int)cnt);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(st->mul_done[k], cx->stream));
+            HIP_TRY(hipStreamWaitEvent(st->d2h, st->mul_done[k], 0));
+            if (pin_o && ab_stride == out_len) {
+                HIP_TRY(hipMemcpyAsync(ab + s * S * ab_stride, st->dout[k].ptr, cnt * out_len * 4, hipMemcpyDeviceToHost, st->d2h));
+            } else if (pin_o) {
+                HIP_TRY(hipMemcpy2DAsync(ab + s * S * ab_stride, ab_stride * 4, st->dout[k].ptr, out_len * 4, out_len * 4,
+                                         cnt, hipMemcpyDeviceToHost, st->d2h));
+            } else {
+                HIP_TRY(hipMemcpyAsync(st->hout[k].ptr, st->dout[k].ptr, cnt * out_len * 4, hipMemcpyDeviceToHost, st->d2h));
+            }
+            HIP_TRY(hipEventRecord(st->out_done[k], st->d2h));
         }
-        HIP_TRY(hipEventRecord(st->out_done[k], st->d2h));
-    }
-    for (size_t s = slices > (size_t)kRing ? slices - kRing : 0; s < slices; ++s)
-        if ((rc = finalize(s))) return rc;
-    HIP_TRY(hipStreamSynchronize(st->d2h));
-    HIP_TRY(hipStreamSynchronize(st->h2d));
-    HIP_TRY(hipStreamSynchronize(cx->stream));
-    return NTT_OK;
+        for (size_t s = slices > (size_t)kRing ? slices - kRing : 0; s < slices; ++s)
+            if ((rc = finalize(s))) return rc;
+        HIP_TRY(hipStreamSynchronize(st->d2h));
+        HIP_TRY(hipStreamSynchronize(st->h2d));
+        HIP_TRY(hipStreamSynchronize(cx->stream));
+        return NTT_OK;
+    };
+    // Whatever ends the call -- a status or an exception -- nothing of it may still be in flight afterwards: the
+    // copies read and write the caller's arrays, and the next call relies on a drained ring.
+    struct Drain {
+        StreamState *st;
+        ntt_ctx *cx;
+        bool armed = true;
+        ~Drain()
+        {
+            if (!armed) return;
+            (void)hipStreamSynchronize(st->h2d);
+            (void)hipStreamSynchronize(cx->stream);
+            (void)hipStreamSynchronize(st->d2h);
+        }
+    } drain{st, cx};
+    rc = run();
+    if (rc == NTT_OK) drain.armed = false;
+    return rc;
 }
 NTT_CATCH_STATUS
