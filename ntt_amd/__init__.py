@@ -119,13 +119,23 @@ def _check(rc):
         raise NttError(rc, _lib.ntt_last_error().decode("utf-8", "replace"))
 
 
-def _ptr(x, dtype):
-    """Raw address of a numpy array (host) or of an object with data_ptr() (device tensor)."""
+def _ptr(x, dtype, need=0):
+    """Raw address of a numpy array (host) or of an object with data_ptr() (device tensor), after checking
+    on the host what the kernels assume: element width, contiguity and at least `need` elements."""
+    width = np.dtype(dtype).itemsize
     if hasattr(x, "data_ptr"):
-        return C.c_void_p(x.data_ptr())
-    if not isinstance(x, np.ndarray) or x.dtype != dtype or not x.flags["C_CONTIGUOUS"]:
-        raise TypeError(f"expected a C-contiguous numpy array of {np.dtype(dtype)} or a device tensor")
-    return C.c_void_p(x.ctypes.data)
+        if x.element_size() != width or not x.is_contiguous():
+            raise TypeError(f"expected a contiguous tensor with {width}-byte elements")
+        have = x.numel()
+        addr = x.data_ptr()
+    else:
+        if not isinstance(x, np.ndarray) or x.dtype != dtype or not x.flags["C_CONTIGUOUS"]:
+            raise TypeError(f"expected a C-contiguous numpy array of {np.dtype(dtype)} or a device tensor")
+        have = x.size
+        addr = x.ctypes.data
+    if have < need:
+        raise ValueError(f"array of {have} elements where the call reads or writes {need}")
+    return C.c_void_p(addr)
 
 
 class Context:
@@ -176,8 +186,8 @@ class Context:
         n = int(a.shape[-1]) if hasattr(a, "shape") else len(a)
         if out is None:
             out = np.zeros(2 * n - 1, dtype=np.uint64)
-        _check(_lib.ntt_crt_multiply(self._h, _ptr(a, np.uint64), _ptr(b, np.uint64),
-                                     _ptr(out, np.uint64), n, int(p64)))
+        _check(_lib.ntt_crt_multiply(self._h, _ptr(a, np.uint64, n), _ptr(b, np.uint64, n),
+                                     _ptr(out, np.uint64, 2 * n - 1), n, int(p64)))
         return out
 
     def crt_multiply_batched(self, a, b, p64, out=None):
@@ -185,8 +195,8 @@ class Context:
         batch, n = int(a.shape[0]), int(a.shape[1])
         if out is None:
             out = np.zeros((batch, 2 * n - 1), dtype=np.uint64)
-        _check(_lib.ntt_crt_multiply_batched(self._h, _ptr(a, np.uint64), _ptr(b, np.uint64),
-                                             _ptr(out, np.uint64), n, int(p64), batch))
+        _check(_lib.ntt_crt_multiply_batched(self._h, _ptr(a, np.uint64, batch * n), _ptr(b, np.uint64, batch * n),
+                                             _ptr(out, np.uint64, batch * (2 * n - 1)), n, int(p64), batch))
         return out
 
     def crt_residue_multiply(self, a, b, prime_index, out=None):
@@ -194,8 +204,8 @@ class Context:
         n = int(a.shape[-1])
         if out is None:
             out = np.zeros(2 * n - 1, dtype=np.uint32)
-        _check(_lib.ntt_crt_residue_multiply(self._h, _ptr(a, np.uint64), _ptr(b, np.uint64),
-                                             _ptr(out, np.uint32), n, int(prime_index)))
+        _check(_lib.ntt_crt_residue_multiply(self._h, _ptr(a, np.uint64, n), _ptr(b, np.uint64, n),
+                                             _ptr(out, np.uint32, 2 * n - 1), n, int(prime_index)))
         return out
 
     def crt_merge(self, rows, p64, out=None, count=None):
@@ -204,7 +214,7 @@ class Context:
             count = int(rows[0].shape[-1])
         if out is None:
             out = np.zeros(count, dtype=np.uint64)
-        _check(_lib.ntt_crt_merge(self._h, *[_ptr(r, np.uint32) for r in rows], _ptr(out, np.uint64),
+        _check(_lib.ntt_crt_merge(self._h, *[_ptr(r, np.uint32, count) for r in rows], _ptr(out, np.uint64, count),
                                   count, int(p64)))
         return out
 
@@ -269,8 +279,9 @@ class Plan:
             out_stride = 2 * self.n - 1
         if out is None:
             out = np.zeros((batch, out_stride), dtype=np.uint32)
-        _check(_lib.ntt_poly_multiply_batched(self._h, _ptr(a, np.uint32), _ptr(b, np.uint32),
-                                              _ptr(out, np.uint32), out_stride, batch))
+        need_out = (batch - 1) * out_stride + 2 * self.n - 1
+        _check(_lib.ntt_poly_multiply_batched(self._h, _ptr(a, np.uint32, batch * self.n), _ptr(b, np.uint32, batch * self.n),
+                                              _ptr(out, np.uint32, need_out), out_stride, batch))
         return out
 
     def multiply_stream(self, a, b, out=None, out_stride=None):
@@ -281,16 +292,17 @@ class Plan:
             out_stride = 2 * self.n - 1
         if out is None:
             out = np.zeros((count, out_stride), dtype=np.uint32)
-        _check(_lib.ntt_poly_multiply_stream(self._h, _ptr(a, np.uint32), _ptr(b, np.uint32),
-                                             _ptr(out, np.uint32), out_stride, count))
+        need_out = (count - 1) * out_stride + 2 * self.n - 1 if count else 0
+        _check(_lib.ntt_poly_multiply_stream(self._h, _ptr(a, np.uint32, count * self.n), _ptr(b, np.uint32, count * self.n),
+                                             _ptr(out, np.uint32, need_out), out_stride, count))
         return out
 
     def forward(self, data, batch=1):
-        _check(_lib.ntt_forward(self._h, _ptr(data, np.uint32), batch))
+        _check(_lib.ntt_forward(self._h, _ptr(data, np.uint32, batch * self.length), batch))
         return data
 
     def inverse(self, data, batch=1):
-        _check(_lib.ntt_inverse(self._h, _ptr(data, np.uint32), batch))
+        _check(_lib.ntt_inverse(self._h, _ptr(data, np.uint32, batch * self.length), batch))
         return data
 
 
@@ -312,8 +324,9 @@ class NegacyclicPlan(Plan):
             out_stride = self.n
         if out is None:
             out = np.zeros((batch, out_stride), dtype=np.uint32)
-        _check(_lib.ntt_negacyclic_multiply_batched(self._h, _ptr(a, np.uint32), _ptr(b, np.uint32),
-                                                    _ptr(out, np.uint32), out_stride, batch))
+        need_out = (batch - 1) * out_stride + self.n
+        _check(_lib.ntt_negacyclic_multiply_batched(self._h, _ptr(a, np.uint32, batch * self.n), _ptr(b, np.uint32, batch * self.n),
+                                                    _ptr(out, np.uint32, need_out), out_stride, batch))
         return out
 
 
@@ -350,7 +363,9 @@ class Plan64:
         if out is None:
             out = np.zeros((batch, out_stride), dtype=np.uint64)
         fn = _lib.ntt_negacyclic_multiply64_batched if self.negacyclic else _lib.ntt_poly_multiply64_batched
-        _check(fn(self._h, _ptr(a, np.uint64), _ptr(b, np.uint64), _ptr(out, np.uint64), out_stride, batch))
+        need_out = (batch - 1) * out_stride + (self.n if self.negacyclic else 2 * self.n - 1)
+        _check(fn(self._h, _ptr(a, np.uint64, batch * self.n), _ptr(b, np.uint64, batch * self.n),
+                  _ptr(out, np.uint64, need_out), out_stride, batch))
         return out
 
 
@@ -377,12 +392,12 @@ class DistPlan:
 
     def colpass(self, data, inverse=False):
         """In place on the [world][S/world] device array held after the first all-to-all."""
-        _check(_lib.ntt_dist_colpass(self._h, _ptr(data, np.uint32), 1 if inverse else 0))
+        _check(_lib.ntt_dist_colpass(self._h, _ptr(data, np.uint32, self.local_length), 1 if inverse else 0))
         return data
 
     def local(self, row, inverse=False):
         """S-point transform (natural order) of this rank's row, in place."""
-        _check(_lib.ntt_dist_local(self._h, _ptr(row, np.uint32), 1 if inverse else 0))
+        _check(_lib.ntt_dist_local(self._h, _ptr(row, np.uint32, self.local_length), 1 if inverse else 0))
         return row
 
 

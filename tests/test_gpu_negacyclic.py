@@ -155,7 +155,9 @@ def test_negacyclic_errors(nt, ctx):
         nt._check(nt._lib.ntt_negacyclic_multiply_batched(lin._h, a.ctypes.data, a.ctypes.data,
                                                           np.zeros((2, 64), dtype=np.uint32).ctypes.data, 64, 2))
     with pytest.raises(nt.NttError):
-        plan.multiply(a, a, out=np.zeros((2, 32), dtype=np.uint32), out_stride=32)
+        plan.multiply(a, a, out=np.zeros((2, 64), dtype=np.uint32), out_stride=32)   # stride below the row length
+    with pytest.raises(ValueError):
+        plan.multiply(a, a, out=np.zeros((2, 32), dtype=np.uint32), out_stride=64)   # the binding's own size check
     plan.close()
     lin.close()
 

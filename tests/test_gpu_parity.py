@@ -646,7 +646,8 @@ def test_errors(nt, ctx):
         ctx.crt_multiply(np.zeros(4, np.uint64), np.zeros(4, np.uint64), 1 << 61)   # even / too big
     plan = ctx.plan(998244353, 16, 1)
     with pytest.raises(nt.NttError):
-        plan.multiply(np.zeros((1, 16), np.uint32), np.zeros((1, 16), np.uint32), out_stride=10)
+        plan.multiply(np.zeros((1, 16), np.uint32), np.zeros((1, 16), np.uint32), out=np.zeros(31, np.uint32),
+                      out_stride=10)          # stride below the row length: the library's own check
     with pytest.raises(nt.NttError):               # more products than the plan was sized for
         plan.multiply(np.zeros((2, 16), np.uint32), np.zeros((2, 16), np.uint32))
     plan.close()
@@ -714,3 +715,37 @@ def test_concurrent_callers(nt, ctx):
         pl.close()
     ctx2.close()
     assert not errors, errors
+
+
+def test_binding_checks_shapes_before_launching(nt, ctx):
+    """The Python binding refuses what would make a kernel read or write out of bounds: short arrays,
+    non-contiguous tensors, wrong element width -- before any launch."""
+    import torch
+    n = 4096
+    plan = ctx.plan(998244353, n, 2)
+    a = np.ones((2, n), dtype=np.uint32)
+    with pytest.raises(ValueError):
+        plan.multiply(a, a[:1], batch=2)                       # b holds one row
+    with pytest.raises(ValueError):
+        plan.multiply(a, a, out=np.zeros(2 * n - 1, dtype=np.uint32), batch=2)
+    with pytest.raises(TypeError):
+        plan.multiply(a.astype(np.uint64), a, batch=2)
+    with pytest.raises(TypeError):
+        plan.multiply(np.ones((2, 2 * n), dtype=np.uint32)[:, ::2], a, batch=2)
+    t = torch.ones((2, 2 * n), dtype=torch.int32, device="cuda")
+    with pytest.raises(TypeError):
+        plan.multiply(t[:, ::2], t[:, ::2], batch=2)           # strided device tensor
+    with pytest.raises(TypeError):
+        plan.multiply(t.to(torch.int64), t.to(torch.int64), batch=2)
+    with pytest.raises(ValueError):
+        plan.multiply(t[:1, :n].contiguous(), t[:1, :n].contiguous(), batch=2)
+    with pytest.raises(ValueError):
+        plan.forward(np.ones(plan.length - 1, dtype=np.uint32))
+    plan.close()
+    p64 = ctx.plan64(1337006139375617, n)
+    with pytest.raises(ValueError):
+        p64.multiply(np.ones(n, dtype=np.uint64), np.ones(n - 1, dtype=np.uint64))
+    p64.close()
+    with pytest.raises(ValueError):
+        ctx.crt_multiply(np.ones(n, dtype=np.uint64), np.ones(n, dtype=np.uint64), 1337006139375617,
+                         out=np.zeros(n, dtype=np.uint64))

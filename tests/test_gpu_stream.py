@@ -93,8 +93,9 @@ def test_stream_errors(nt, ctx):
     plan = ctx.plan(P, 64, 2)
     a = np.zeros((3, 64), dtype=np.uint32)
     with pytest.raises(nt.NttError):
-        plan.multiply_stream(a, a, out=np.zeros((3, 100), dtype=np.uint32), out_stride=100)    # stride < 2n-1
+        plan.multiply_stream(a, a, out=np.zeros((3, 127), dtype=np.uint32), out_stride=100)    # stride < 2n-1
     d = torch.zeros((3, 64), dtype=torch.int32, device="cuda")
+    dout = torch.zeros((3, 127), dtype=torch.int32, device="cuda")
     with pytest.raises(nt.NttError):          # device operands belong to ntt_poly_multiply_batched
-        plan.multiply_stream(d, d, out=d, out_stride=127)
+        plan.multiply_stream(d, d, out=dout, out_stride=127)
     plan.close()
