@@ -387,6 +387,7 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
     // negacyclic plans: L = n, no zero padding, n outputs, operands and result twisted by psi^(+-i)
     const bool neg = pl->negacyclic;
     const uint32_t n = (uint32_t)pl->n, L = pl->L, out_len = neg ? n : 2 * n - 1;
+    if (pl->wide) return multiply_device<MM>(pl->wide, a, b, ab, ab_stride, batch);
     pl->ctx->cur = pl->ctx->stream;
     if (pl->logL == kRowLog && pl->twA) {
         Row4096Args<MM> ra{};
@@ -730,6 +731,7 @@ try {
     for (void *d : pl->owned) (void)hipFree(d);
     pl->work0.release();
     pl->work1.release();
+    if (pl->wide) ntt_plan_destroy(pl->wide);
     delete pl;
     return NTT_OK;
 }
@@ -760,7 +762,8 @@ try {
 }
 NTT_CATCH_STATUS
 
-static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind, bool negacyclic, ntt_plan **out_plan);
+static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind, bool negacyclic, ntt_plan **out_plan,
+                       int force_logL = 0);
 
 int ntt_plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind, ntt_plan **out_plan)
 try {
@@ -775,7 +778,8 @@ try {
 }
 NTT_CATCH_STATUS
 
-static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind, bool negacyclic, ntt_plan **out_plan)
+static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_kind, bool negacyclic, ntt_plan **out_plan,
+                       int force_logL)
 {
     if (!ctx || !out_plan) return fail(NTT_ERR_INVALID, "ntt_plan_create: null argument");
     *out_plan = nullptr;
@@ -788,6 +792,7 @@ static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_ki
     int logL = 1;
     while ((1u << logL) < 2u * (uint32_t)n) ++logL;
     if (negacyclic) --logL;                               // x^n + 1: transform length n, 2n-th root psi
+    if (force_logL > logL) logL = force_logL;             // companion plan: longer zero-padded transform
     const uint32_t L = 1u << logL;
     if ((p - 1) % (negacyclic ? 2 * (uint64_t)L : (uint64_t)L) != 0)
         return fail(NTT_ERR_UNSUPPORTED, "ntt_plan_create: p - 1 is not divisible by the transform length (p is not NTT-friendly for this n)");
@@ -855,6 +860,14 @@ static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_ki
     int rc = modmul_kind == NTT_MODMUL_MONTGOMERY ? build_tables<Mont32>(pl.get())
                                                   : build_tables<Barrett32>(pl.get());
     if (rc) { ntt_plan *raw = pl.release(); ntt_plan_destroy(raw); return rc; }
+    if (!negacyclic && logL == kRowLog - 1 && force_logL == 0 && (p - 1) % (1u << kRowLog) == 0) {
+        bool want = true;
+        if (const char *e = std::getenv("NTT_AMD_WIDE2048")) want = e[0] != '0';
+        if (want) {
+            rc = plan_create(ctx, p, n, batch, modmul_kind, false, &pl->wide, kRowLog);
+            if (rc) { ntt_plan *raw = pl.release(); ntt_plan_destroy(raw); return rc; }
+        }
+    }
     *out_plan = pl.release();
     return NTT_OK;
 }

@@ -108,6 +108,10 @@ struct ntt_plan {
     // negacyclic plans (products modulo x^n + 1, L = n): psi^i and psi^-i, psi = g^((p-1)/2n);
     // small_itwist = psi^-i with the multiply scale folded in (L <= 4096 path)
     bool negacyclic = false;
+    // products of 512 < n <= 1024 coefficients (L = 2048): the 4096-point row kernel on zero-padded rows is
+    // twice as fast as the LDS kernel at its natural length (0.021 vs 0.041 us per product), so the
+    // multiply goes through this companion plan of L = 4096; transforms keep the plan's own length
+    ntt_plan *wide = nullptr;
     void *twist_fwd = nullptr, *twist_inv = nullptr, *small_itwist = nullptr;
     // by-value kernel constants, raw bytes of Roots64<MM> / tw_t
     std::vector<unsigned char> roots, iroots, scale_mul, scale_plain;
