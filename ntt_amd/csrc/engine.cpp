@@ -409,7 +409,7 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
         small_pass<MM>(pl, 0, a, b, ab, n, ab_stride, n, out_len, (unsigned)batch);
         return NTT_OK;
     }
-    if (pl->fused) {                                       // L = 8192 / 16384: column level and rows in one kernel
+    if (pl->fused) {                                       // linear, L = 8192: column level and rows in one kernel
         FusedArgs<MM> fa{};
         fa.r.row = fill_row<MM>(pl, a, b, ab);
         fa.r.in_stride = n; fa.r.out_stride = ab_stride;
@@ -423,7 +423,7 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
         fa.tw_inv = static_cast<const typename MM::tw_t *>(pl->tw_inv[0]);
         ntt_ctx *cx = pl->ctx;
         cx->begin(K_ROW_MUL);
-        launch_fused_product(pl->kind, pl->lazy, pl->level_log[0], !neg, &fa, pl->mp, (unsigned)batch, cx->cur);
+        launch_fused_product(pl->kind, pl->lazy, &fa, pl->mp, (unsigned)batch, cx->cur);
         cx->end();
         return NTT_OK;
     }
@@ -849,14 +849,11 @@ static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_ki
             logM -= pl->level_log[j];
         }
         pl->nlevels = m;
-        // L = 8192, 16384: one kernel does the column level in registers around the rows (kernels_fused.hip)
-        // Measured (tools/sweep_small.py): linear products of L = 8192 0.077 -> 0.043 us; the variants without
-        // the zero-padded upper half (negacyclic) and with N1 = 4 need more registers than three waves per
-        // SIMD leave and lose to the three-kernel path, so they stay on it unless NTT_AMD_FUSED asks.
-        int fused_max = 1;
-        bool fused_full = false;
-        if (const char *e = std::getenv("NTT_AMD_FUSED")) { fused_max = std::atoi(e); fused_full = fused_max > 0; }
-        pl->fused = m == 1 && pl->level_log[0] <= fused_max && (!negacyclic || fused_full);
+        // linear products of L = 8192: one kernel does the column level in registers around the rows (kernels_fused.hip)
+        // (0.077 -> 0.043 us per product, tools/sweep_small.py; NTT_AMD_FUSED=0 keeps the three kernels)
+        bool fused_ok = true;
+        if (const char *e = std::getenv("NTT_AMD_FUSED")) fused_ok = e[0] != '0';
+        pl->fused = fused_ok && m == 1 && pl->level_log[0] == 1 && !negacyclic;
         // work buffers: two operands per product, `chunk` products per launch and per lane.
         // Measured (profiles/sweep_chunk_r01.txt, profiles/sweep_chunk_r01d.txt): throughput rises
         // with the chunk up to ~40 products (fewer launches, smaller tail rounds), is flat from 40

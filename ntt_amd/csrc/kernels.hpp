@@ -59,7 +59,7 @@ struct Row4096Args {
     const typename MM::tw_t *twist, *itwist;     // negacyclic: psi^i, and psi^-i with `scale` folded in
 };
 
-// A whole product of L = 8192 / 16384 in one kernel (kernels_fused.hip): Row4096Args plus the level-0 column
+// A whole linear product of L = 8192 in one kernel (kernels_fused.hip): Row4096Args plus the level-0 column
 // tables [N1][4096]; r.itwist here is the plain psi^-i table (the scale sits in `r.scale` and `tw_inv`).
 template <class MM>
 struct FusedArgs {
@@ -203,7 +203,7 @@ struct Row64Args {
     const uint64_t *itwA, *itwB;         // inverse
     Roots16x64 roots, iroots;
 };
-void launch_fused_product(int kind, bool lazy, int logN1, bool half_in, const void *args, const ModParams &mp,
+void launch_fused_product(int kind, bool lazy, const void *args, const ModParams &mp,
                           unsigned batch, hipStream_t s);
 void launch_row64_mul(const Row64Args &a, const ModParams64 &mp, unsigned rows, hipStream_t s);
 void launch_col64(int logN1, bool inverse, bool half_in, const Col64Args &a, const ModParams64 &mp,

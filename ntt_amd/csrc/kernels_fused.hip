@@ -11,8 +11,15 @@
 // written once; nothing else touches memory.  Same tables as the three-kernel path (level-0 column
 // twiddles, row tables), same arithmetic, same results.
 //
+// Shipped for N1 = 2 with a zero upper half only, i.e. linear products of 2048 < n <= 4096 (0.077 -> 0.043 us
+// per product, tools/sweep_small.py).  Tried and left on the three-kernel path, each parity-green but slower
+// than it: the full-length input of a negacyclic product (twice the loads and the twist: 246 VGPRs, or 168
+// with spills; also with operand a's spectra parked in LDS, and with buffer-descriptor addressing), N1 = 4
+// (128 data registers), and a form with 256 * N1 threads and one row per four-wave thread group (registers
+// fit, but with one or two workgroups per CU nothing runs while a group waits at its barriers).
+//
 // Replaces, like the kernels it fuses, the stages of NTT_iterative (main-montgomery.cc:255-295) and the
-// pointwise loop (:341-344) for n in (2048, 8192] (negacyclic: n = 8192, 16384).
+// pointwise loop (:341-344) for n in (2048, 4096].
 #include "row_body.hpp"
 
 namespace ntt {
@@ -79,10 +86,7 @@ __global__ void __launch_bounds__(256, NTT_FUSED_WAVES) fused_product_kernel(con
     // this body, and a rolled loop would index the register arrays dynamically)
     fused_row<MM, LAZY>(xa[0], xb[0], lds, t, a.r.row, m);
     fused_row<MM, LAZY>(xa[1], xb[1], lds, t, a.r.row, m);
-    if constexpr (N1 == 4) {
-        fused_row<MM, LAZY>(xa[2], xb[2], lds, t, a.r.row, m);
-        fused_row<MM, LAZY>(xa[3], xb[3], lds, t, a.r.row, m);
-    }
+    static_assert(N1 == 2, "two rows per thread: see the header for what was tried beyond");
     uint32_t *__restrict__ po = a.r.row.out + (size_t)blockIdx.x * a.r.out_stride;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -104,29 +108,22 @@ __global__ void __launch_bounds__(256, NTT_FUSED_WAVES) fused_product_kernel(con
 }
 
 template <class MM, bool LAZY>
-static void launch_fused_t(int logN1, bool half_in, const FusedArgs<MM> &a, const ModParams &mp, unsigned batch, hipStream_t s)
+static void launch_fused_t(const FusedArgs<MM> &a, const ModParams &mp, unsigned batch, hipStream_t s)
 {
-    const dim3 g(batch), b(256);
-    if (logN1 == 1) {
-        if (half_in) hipLaunchKernelGGL((fused_product_kernel<MM, LAZY, 1, true>), g, b, 0, s, a, mp);
-        else hipLaunchKernelGGL((fused_product_kernel<MM, LAZY, 1, false>), g, b, 0, s, a, mp);
-    } else {
-        if (half_in) hipLaunchKernelGGL((fused_product_kernel<MM, LAZY, 2, true>), g, b, 0, s, a, mp);
-        else hipLaunchKernelGGL((fused_product_kernel<MM, LAZY, 2, false>), g, b, 0, s, a, mp);
-    }
+    hipLaunchKernelGGL((fused_product_kernel<MM, LAZY, 1, true>), dim3(batch), dim3(256), 0, s, a, mp);
 }
 
-void launch_fused_product(int kind, bool lazy, int logN1, bool half_in, const void *args, const ModParams &mp,
+void launch_fused_product(int kind, bool lazy, const void *args, const ModParams &mp,
                           unsigned batch, hipStream_t s)
 {
     if (kind == 0) {
         const auto &a = *static_cast<const FusedArgs<Mont32> *>(args);
-        if (lazy) launch_fused_t<Mont32, true>(logN1, half_in, a, mp, batch, s);
-        else launch_fused_t<Mont32, false>(logN1, half_in, a, mp, batch, s);
+        if (lazy) launch_fused_t<Mont32, true>(a, mp, batch, s);
+        else launch_fused_t<Mont32, false>(a, mp, batch, s);
     } else {
         const auto &a = *static_cast<const FusedArgs<Barrett32> *>(args);
-        if (lazy) launch_fused_t<Barrett32, true>(logN1, half_in, a, mp, batch, s);
-        else launch_fused_t<Barrett32, false>(logN1, half_in, a, mp, batch, s);
+        if (lazy) launch_fused_t<Barrett32, true>(a, mp, batch, s);
+        else launch_fused_t<Barrett32, false>(a, mp, batch, s);
     }
 }
 
