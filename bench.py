@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="products per kernel launch (0 = library default)")
     ap.add_argument("--no-check", action="store_true",
                     help="skip the result checks (timing-only ablation builds whose results are wrong on purpose)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="rendezvous backend for N > 1; gloo lets ranks share a GPU to rehearse the multi-rank flow on a one-GPU box")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket kernels with HIP events in the timed region (no roofline block)")
     args = ap.parse_args()
@@ -121,8 +123,10 @@ def main():
     from ntt_amd import shard
 
     rank, world, local_rank = shard.env_rank_world()
+    if args.backend == "gloo":                        # rehearsal: ranks may share a GPU, exchanges on host tensors
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
-    group = shard.Group("nccl", device=torch.device("cuda", local_rank))     # RCCL when world > 1
+    group = shard.Group(args.backend, device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)   # RCCL when world > 1
 
     B, n, p = args.batch, args.n, args.p
     stride = 2 * n
