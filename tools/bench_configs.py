@@ -194,6 +194,62 @@ def main():
     for pl in nplans:
         pl.close()
 
+    # ---- the same ring with 64-bit limbs (FHE moduli of ~50 bits): 16 primes k * 2^17 + 1 just below 2^50 and,
+    # for the Montgomery lanes, just below 2^62; 64 pairs per limb
+    def is_prime(q):
+        if q % 2 == 0:
+            return q == 2
+        d, s = q - 1, 0
+        while d % 2 == 0:
+            d //= 2
+            s += 1
+        for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+            if q % a == 0:
+                return q == a
+            x = pow(a, d, q)
+            if x in (1, q - 1):
+                continue
+            for _ in range(s - 1):
+                x = x * x % q
+                if x == q - 1:
+                    break
+            else:
+                return False
+        return True
+
+    def primes_below(bits, count):
+        out, k = [], (1 << bits) >> 17
+        while len(out) < count:
+            k -= 1
+            if is_prime(k * (1 << 17) + 1):
+                out.append(k * (1 << 17) + 1)
+        return out
+
+    per64 = 64
+    rng64 = np.random.default_rng(64)
+    for bits, label in ((50, "exact-integer FP64 lanes"), (62, "64-bit Montgomery lanes")):
+        primes64 = primes_below(bits, 16)
+        ya = torch.from_numpy(rng64.integers(0, primes64[-1], size=(per64, n), dtype=np.uint64).view(np.int64)).cuda()
+        yb = torch.from_numpy(rng64.integers(0, primes64[-1], size=(per64, n), dtype=np.uint64).view(np.int64)).cuda()
+        yout = torch.zeros((per64, n), dtype=torch.int64, device="cuda")
+        plans64 = [ctx.negacyclic_plan64(q, n, per64) for q in primes64]
+
+        def step64():
+            for pl in plans64:
+                pl.multiply(ya, yb, out=yout, batch=per64)
+
+        step64()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step64()
+        sync()
+        dt = (time.perf_counter() - t0) / reps
+        print(json.dumps({"config": f"4 negacyclic with 64-bit limbs: n=2^16, 16 primes below 2^{bits} x 64 pairs ({label})",
+                          "ms_per_batch": dt * 1e3, "poly_mults_per_s": 16 * per64 / dt}), flush=True)
+        for pl in plans64:
+            pl.close()
+
     # ---- config 5 ------------------------------------------------------------------------------
     p, L = 469762049, 1 << 26
     x = torch.from_numpy((orc.splitmix64_np(7, L) % np.uint64(p)).astype(np.uint32).view(np.int32)).cuda()
