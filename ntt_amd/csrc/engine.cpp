@@ -434,8 +434,9 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
     int lanes = std::min(std::min(pl->lanes, cx->nlanes), nchunks);
     if (cx->lane_limit > 0) lanes = std::min(lanes, cx->lane_limit);
     if (lanes > 1) {                                      // fork: side lanes start after prior work
-        (void)hipEventRecord(cx->fork_ev, cx->stream);
-        for (int l = 1; l < lanes; ++l) (void)hipStreamWaitEvent(cx->lane[l], cx->fork_ev, 0);
+        // ordering between the lanes is what keeps the results right: a failure here is an error, not a warning
+        HIP_TRY(hipEventRecord(cx->fork_ev, cx->stream));
+        for (int l = 1; l < lanes; ++l) HIP_TRY(hipStreamWaitEvent(cx->lane[l], cx->fork_ev, 0));
     }
     int ci = 0;
     for (int c0 = 0; c0 < batch; c0 += pl->chunk, ++ci) {
@@ -463,8 +464,8 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
     cx->cur = cx->stream;
     if (lanes > 1) {                                      // join
         for (int l = 1; l < lanes; ++l) {
-            (void)hipEventRecord(cx->lane_done[l], cx->lane[l]);
-            (void)hipStreamWaitEvent(cx->stream, cx->lane_done[l], 0);
+            HIP_TRY(hipEventRecord(cx->lane_done[l], cx->lane[l]));
+            HIP_TRY(hipStreamWaitEvent(cx->stream, cx->lane_done[l], 0));
         }
     }
     return NTT_OK;
@@ -610,7 +611,7 @@ hipEvent_t ntt_ctx::grab_event()
         return e;
     }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) e = nullptr;      // begin() then leaves this launch untimed
     return e;
 }
 void ntt_ctx::begin(int id)
@@ -618,7 +619,12 @@ void ntt_ctx::begin(int id)
     stamp_open = timing && (timing_only < 0 || timing_only == id);
     if (!stamp_open) return;
     Stamp s{id, grab_event(), grab_event()};
-    (void)hipEventRecord(s.e0, cur ? cur : stream);
+    if (!s.e0 || !s.e1 || hipEventRecord(s.e0, cur ? cur : stream) != hipSuccess) {   // timing is diagnostic only
+        if (s.e0) event_pool.push_back(s.e0);
+        if (s.e1) event_pool.push_back(s.e1);
+        stamp_open = false;
+        return;
+    }
     stamps.push_back(s);
 }
 void ntt_ctx::end()
@@ -681,7 +687,10 @@ try {
             break;
         }
     }
-    (void)hipEventCreateWithFlags(&cx->fork_ev, hipEventDisableTiming);
+    if (hipEventCreateWithFlags(&cx->fork_ev, hipEventDisableTiming) != hipSuccess) {
+        cx->fork_ev = nullptr;
+        cx->nlanes = 1;                                    // no fork event: single lane
+    }
     *out_ctx = cx;
     return NTT_OK;
 }
