@@ -326,6 +326,8 @@ static int plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, bool nega
         return fail(NTT_ERR_UNSUPPORTED, "ntt_plan64_create: p64 - 1 is not divisible by the transform length");
     if ((uint64_t)batch << lg > (1ull << 29))
         return fail(NTT_ERR_UNSUPPORTED, "ntt_plan64_create: batch * L above 2^29 elements");
+    if (lg > kRowLog && batch > 65535)                            // the column kernels index the batch with blockIdx.y
+        return fail(NTT_ERR_UNSUPPORTED, "ntt_plan64_create: batch above 65535 for a transform longer than 4096");
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     auto *pl = new ntt_plan64();

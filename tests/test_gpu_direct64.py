@@ -216,6 +216,8 @@ def test_direct64_errors(nt, ctx):
         ctx.plan64(P33, 1 << 20)                # 2-adicity 20 < 21
     with pytest.raises(nt.NttError):
         ctx.plan64(18446744069414584321, 16)    # NTT-friendly but above 2^62
+    with pytest.raises(nt.NttError):
+        ctx.plan64(P51, 4096, batch=65536)      # L = 8192: the column kernels take at most 65535 rows per launch
     plan = ctx.plan64(P51, 16, batch=2)
     a = np.zeros((3, 16), dtype=np.uint64)
     with pytest.raises(nt.NttError):
