@@ -112,6 +112,7 @@ struct ntt_plan {
     // twice as fast as the LDS kernel at its natural length (0.021 vs 0.041 us per product), so the
     // multiply goes through this companion plan of L = 4096; transforms keep the plan's own length
     ntt_plan *wide = nullptr;
+    bool fold2048 = false;                // companion of a negacyclic n = 2048 plan: linear product of L = 4096, folded at the store
     bool fused = false;                   // L = 8192 / 16384 products run in fused_product_kernel
     void *twist_fwd = nullptr, *twist_inv = nullptr, *small_itwist = nullptr;
     // by-value kernel constants, raw bytes of Roots64<MM> / tw_t

@@ -57,6 +57,7 @@ struct Row4096Args {
     uint32_t in_len, out_len;
     typename MM::tw_t scale;             // L^-1 (times R for Montgomery's pointwise product)
     const typename MM::tw_t *twist, *itwist;     // negacyclic: psi^i, and psi^-i with `scale` folded in
+    int fold;                            // 1: store c[i] = ab[i] - ab[i + 2048], i < 2048 (x^2048 + 1 from the linear product)
 };
 
 // A whole linear product of L = 8192 in one kernel (kernels_fused.hip): Row4096Args plus the level-0 column

@@ -55,6 +55,16 @@ __global__ void __launch_bounds__(256) row_product_kernel(const Row4096Args<MM> 
     for (int k = 0; k < 16; ++k) xa[k] = O::mul(xa[k], xb[k], m);
     row_inverse<MM, LAZY>(xa, lds, t, a.row, m);              // loose outputs, unscaled
     uint32_t *__restrict__ po = a.row.out + (size_t)blockIdx.x * a.out_stride;
+    if (a.fold) {                                             // x^2048 + 1: position i + 2048 sits in the same thread (uniform)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t i = t + 256 * j;
+            const uint32_t lo = csub(MM::mul_tw(xa[j], a.scale, m), m.p), hi = csub(MM::mul_tw(xa[j + 8], a.scale, m), m.p);
+            const uint32_t d = lo - hi;
+            if (i < a.out_len) po[i] = lo < hi ? d + m.p : d;
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const uint32_t i = t + 256 * j;

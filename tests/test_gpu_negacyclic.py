@@ -73,7 +73,7 @@ def test_negacyclic_tiny_schoolbook(nt, ctx, p):
 
 
 # L = n: small path (<= 4096), one column level of 2 / 16 / 32 / 64 points, two levels (2^19)
-@pytest.mark.parametrize("n", [256, 4096, 8192, 65536, 131072, 262144, 524288])
+@pytest.mark.parametrize("n", [256, 1024, 2048, 4096, 8192, 65536, 131072, 262144, 524288])
 @pytest.mark.parametrize("p,kind", [(P, 0), (P_STRICT, 0), (P_C, 1)])
 def test_negacyclic_vs_linear_oracle(nt, ctx, n, p, kind):
     rng = np.random.default_rng(n + p % 1000)
