@@ -103,8 +103,11 @@ ModParams64 make_params(uint64_t p)
     // p < 2^51: exact integer arithmetic in double-precision lanes (kernels_u64.hip, F64); NTT_AMD_PLAN64_INT=1
     // keeps such a prime on the Montgomery lanes (A/B runs, tests of both policies on one prime)
     const char *e = std::getenv("NTT_AMD_PLAN64_INT");
-    m.fp = (p < (1ull << 51) && !(e && std::atoi(e) != 0)) ? 1 : 0;
+    // NTT_AMD_PLAN64_INT=2 keeps a prime below 2^50 on the general FP64 policy (tests of all three on one prime)
+    const int force = e ? std::atoi(e) : 0;
+    m.fp = force == 1 ? 0 : p < (1ull << 50) && force != 2 ? 2 : p < (1ull << 51) ? 1 : 0;
     m.pd = (double)p;
+    m.pd2 = 2.0 * (double)p;
     m.pinv = 1.0 / (double)p;
     if (m.fp) m.r1 = 1;                                 // no Montgomery factor to cancel in the scale
     return m;

@@ -163,8 +163,8 @@ void launch_crt_merge(const uint32_t *const res[4], uint64_t *out, size_t n, con
 struct ModParams64 {
     uint64_t p, p2, nprime;              // nprime = -p^-1 mod 2^64
     uint64_t r1, r2;                     // 2^64 mod p, 2^128 mod p (host side: table construction)
-    double pd, pinv;                     // F64 policy (p < 2^51): p and 1/p as doubles
-    uint32_t fp;                         // 1: the F64 policy runs (tables hold doubles), 0: Montgomery lanes
+    double pd, pd2, pinv;                // F64 policies: p, 2p and 1/p as doubles
+    uint32_t fp;                         // 0: Montgomery lanes; 1: F64 (p < 2^51), 2: F64L (p < 2^50) -- tables hold doubles
 };
 struct Roots16x64 {
     uint64_t w[8];                       // w_16^j (forward) or w_16^-j (inverse), Montgomery form

@@ -52,13 +52,16 @@ def crt_vectors():
     return np.load(os.path.join(GOLDEN, "crt_vectors.npz"))
 
 
-@pytest.fixture(params=["f64", "int"])
+@pytest.fixture(params=["f64", "f64-general", "int"])
 def lanes64(request, monkeypatch):
-    """Both arithmetic policies of the 64-bit path (kernels_u64.hip): primes below 2^51 run as exact integers
-    in FP64 lanes by default; NTT_AMD_PLAN64_INT=1 (read when a plan is created) keeps them on the Montgomery
-    lanes.  Primes of 51 bits and more take the Montgomery lanes either way."""
+    """The arithmetic policies of the 64-bit path (kernels_u64.hip): primes below 2^51 run as exact integers in
+    FP64 lanes by default (below 2^50 in the variant without the closing fold); NTT_AMD_PLAN64_INT (read when a
+    plan is created) = 2 keeps every such prime on the general FP64 policy, = 1 on the Montgomery lanes.
+    Primes of 51 bits and more take the Montgomery lanes either way."""
     if request.param == "int":
         monkeypatch.setenv("NTT_AMD_PLAN64_INT", "1")
+    elif request.param == "f64-general":
+        monkeypatch.setenv("NTT_AMD_PLAN64_INT", "2")
     else:
         monkeypatch.delenv("NTT_AMD_PLAN64_INT", raising=False)
     return request.param

@@ -69,31 +69,35 @@ def test_direct64_golden(ctx, crt_vectors):
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 64, 2048, 2049, 4096, 10000, 65536, 131072])
-def test_direct64_vs_crt_oracle(ctx, n):
+@pytest.mark.parametrize("p", [P51, P50])
+def test_direct64_vs_crt_oracle(ctx, n, p):
     """Every plan shape: one LDS block (L <= 4096), one column level (L = 8192, 32768), two levels
-    (L = 2^17: 16 x 2, L = 2^18: 16 x 4)."""
+    (L = 2^17: 16 x 2, L = 2^18: 16 x 4); the reference's 51-bit prime (general FP64 policy) and one just
+    below 2^50 (the FP64 policy without the closing fold)."""
     rng = np.random.default_rng(1000 + n)
-    a = rng.integers(0, P51, size=n, dtype=np.uint64)
-    b = rng.integers(0, P51, size=n, dtype=np.uint64)
-    a[0] = P51 - 1
-    b[-1] = P51 - 1
-    want, _ = orc.poly_multiply_crt(a, b, P51, threads=8)
-    plan = ctx.plan64(P51, n)
+    a = rng.integers(0, p, size=n, dtype=np.uint64)
+    b = rng.integers(0, p, size=n, dtype=np.uint64)
+    a[0] = p - 1
+    b[-1] = p - 1
+    want, _ = orc.poly_multiply_crt(a, b, p, threads=8)
+    plan = ctx.plan64(p, n)
     got = plan.multiply(a, b)[0]
     plan.close()
     assert np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("n", [7, 4096, 50000, 65536])
-def test_direct64_top_of_fp64_range(ctx, n):
-    """p just below 2^51, where the rounding bounds of the FP64 multiplication are tightest (|x*w/p| up to
-    2^52): random and all-(p-1) operands against the CRT oracle (n * p^2 < product of its primes up to 2^17)."""
+@pytest.mark.parametrize("p", [P51B, P50])
+def test_direct64_top_of_fp64_range(ctx, n, p):
+    """p just below 2^51 and just below 2^50, where the rounding bounds of the two FP64 policies are tightest
+    (|x*w/p| up to 2^52): random and all-(p-1) operands against the CRT oracle (n * p^2 < product of its
+    primes up to 2^17)."""
     rng = np.random.default_rng(51 + n)
-    plan = ctx.plan64(P51B, n)
-    for a, b in ((rng.integers(0, P51B, size=n, dtype=np.uint64), rng.integers(0, P51B, size=n, dtype=np.uint64)),
-                 (np.full(n, P51B - 1, dtype=np.uint64), np.full(n, P51B - 1, dtype=np.uint64)),
-                 (np.full(n, P51B - 1, dtype=np.uint64), np.ones(n, dtype=np.uint64))):
-        want, _ = orc.poly_multiply_crt(a, b, P51B, threads=8)
+    plan = ctx.plan64(p, n)
+    for a, b in ((rng.integers(0, p, size=n, dtype=np.uint64), rng.integers(0, p, size=n, dtype=np.uint64)),
+                 (np.full(n, p - 1, dtype=np.uint64), np.full(n, p - 1, dtype=np.uint64)),
+                 (np.full(n, p - 1, dtype=np.uint64), np.ones(n, dtype=np.uint64))):
+        want, _ = orc.poly_multiply_crt(a, b, p, threads=8)
         assert np.array_equal(plan.multiply(a, b)[0], want)
     plan.close()
 

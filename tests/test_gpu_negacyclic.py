@@ -190,18 +190,19 @@ def fold(ab, n, p):
 
 
 @pytest.mark.parametrize("n", [2, 8, 256, 4096, 8192, 65536, 131072])
-def test_negacyclic64_vs_linear_crt_oracle(ctx, n, lanes64):
+@pytest.mark.parametrize("p", [P51, 1125899437080577])          # the reference's 51-bit prime, and one just below 2^50
+def test_negacyclic64_vs_linear_crt_oracle(ctx, n, p, lanes64):
     """Small block (L <= 4096), one column level, two levels; against the 4-prime CRT oracle's linear product."""
     rng = np.random.default_rng(n)
-    a = rng.integers(0, P51, size=n, dtype=np.uint64)
-    b = rng.integers(0, P51, size=n, dtype=np.uint64)
-    a[-1] = P51 - 1
-    b[-1] = P51 - 1
-    lin, _ = orc.poly_multiply_crt(a, b, P51, threads=8)
-    plan = ctx.negacyclic_plan64(P51, n)
+    a = rng.integers(0, p, size=n, dtype=np.uint64)
+    b = rng.integers(0, p, size=n, dtype=np.uint64)
+    a[-1] = p - 1
+    b[-1] = p - 1
+    lin, _ = orc.poly_multiply_crt(a, b, p, threads=8)
+    plan = ctx.negacyclic_plan64(p, n)
     got = plan.multiply(a, b)[0]
     plan.close()
-    assert np.array_equal(got, fold(lin, n, P51))
+    assert np.array_equal(got, fold(lin, n, p))
 
 
 def test_negacyclic64_golden_and_schoolbook(ctx, crt_vectors, lanes64):

@@ -13,7 +13,7 @@ import torch  # noqa: E402
 import ntt_amd  # noqa: E402
 import orc  # noqa: E402
 
-p64, n, B = 1337006139375617, 131072, 64
+p64, n, B = int(os.environ.get("P64", "1337006139375617")), 131072, 64
 ctx = ntt_amd.Context(0)
 plan = ctx.plan64(p64, n, batch=B)
 xa = torch.from_numpy((orc.splitmix64_np(5, B * n) % np.uint64(p64)).view(np.int64).reshape(B, n)).cuda()
