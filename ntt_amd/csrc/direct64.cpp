@@ -261,38 +261,48 @@ int multiply_device(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64
         HIP_TRY(hipGetLastError());
         return NTT_OK;
     }
-    int rc = pl->work0.ensure((size_t)pl->batch * L * 8);
-    if (!rc) rc = pl->work1.ensure((size_t)pl->batch * L * 8);
+    // equal chunks of at most 96 MiB per work buffer (48 products at L = 2^18): the intermediates of a launch
+    // sequence stay inside the 256 MiB Infinity Cache (tools/sweep_batch64.py: 5.25 us per product at 32-48 per
+    // launch, 5.6 at 128), and the work buffers do not grow with the batch
+    const int cap = (int)std::max<size_t>(1, std::min<size_t>((size_t)pl->batch, ((size_t)96 << 20) / ((size_t)L * 8)));
+    const int chunk = (batch + (batch + cap - 1) / cap - 1) / ((batch + cap - 1) / cap);      // equal shares, none above cap
+    int rc = pl->work0.ensure((size_t)cap * L * 8);
+    if (!rc) rc = pl->work1.ensure((size_t)cap * L * 8);
     if (rc) return rc;
     uint64_t *w0 = static_cast<uint64_t *>(pl->work0.ptr), *w1 = static_cast<uint64_t *>(pl->work1.ptr);
     const int m = pl->nlevels;
-    // forward column levels, outermost first (operands a and b in one grid)
-    for (int j = 0; j < m; ++j) {
-        const Col64Args ca = j == 0 ? fill_col(pl, 0, false, a, b, w0, w1, n, L, n, L, false)
-                                    : fill_col(pl, j, false, w0, w1, w0, w1, L, L, L, L, false);
-        cx->begin(K_COL64);
-        (pl->level_log[j] >= 5 ? launch_col64x : launch_col64)(pl->level_log[j], false, j == 0 && !neg, ca, pl->mp,
-                                                               L >> pl->level_log[j], (unsigned)batch, 2, s);
-        cx->end();
-    }
-    // rows: forward a, forward b, pointwise, inverse
-    {
-        Row64Args r{};
-        r.a = w0; r.b = w1; r.out = w0;
-        r.twA = pl->twA; r.twB = pl->twB; r.itwA = pl->itwA; r.itwB = pl->itwB;
-        r.roots = pl->roots; r.iroots = pl->iroots;
-        cx->begin(K_LDS64);
-        launch_row64_mul(r, pl->mp, (unsigned)batch * (L >> kRowLog), s);
-        cx->end();
-    }
-    // inverse column levels, innermost first; the outermost writes the caller's ab
-    for (int j = m - 1; j >= 0; --j) {
-        const Col64Args ca = j == 0 ? fill_col(pl, 0, true, w0, nullptr, ab, nullptr, L, ab_stride, L, out_len, true)
-                                    : fill_col(pl, j, true, w0, nullptr, w0, nullptr, L, L, L, L, false);
-        cx->begin(K_COL64);
-        (pl->level_log[j] >= 5 ? launch_col64x : launch_col64)(pl->level_log[j], true, false, ca, pl->mp,
-                                                               L >> pl->level_log[j], (unsigned)batch, 1, s);
-        cx->end();
+    for (int c0 = 0; c0 < batch; c0 += chunk) {
+        const unsigned cb = (unsigned)std::min(chunk, batch - c0);
+        const uint64_t *ca = a + (size_t)c0 * n, *cbp = b + (size_t)c0 * n;
+        uint64_t *cout = ab + (size_t)c0 * ab_stride;
+        // forward column levels, outermost first (operands a and b in one grid)
+        for (int j = 0; j < m; ++j) {
+            const Col64Args ca_ = j == 0 ? fill_col(pl, 0, false, ca, cbp, w0, w1, n, L, n, L, false)
+                                         : fill_col(pl, j, false, w0, w1, w0, w1, L, L, L, L, false);
+            cx->begin(K_COL64);
+            (pl->level_log[j] >= 5 ? launch_col64x : launch_col64)(pl->level_log[j], false, j == 0 && !neg, ca_, pl->mp,
+                                                                   L >> pl->level_log[j], cb, 2, s);
+            cx->end();
+        }
+        // rows: forward a, forward b, pointwise, inverse
+        {
+            Row64Args r{};
+            r.a = w0; r.b = w1; r.out = w0;
+            r.twA = pl->twA; r.twB = pl->twB; r.itwA = pl->itwA; r.itwB = pl->itwB;
+            r.roots = pl->roots; r.iroots = pl->iroots;
+            cx->begin(K_LDS64);
+            launch_row64_mul(r, pl->mp, cb * (L >> kRowLog), s);
+            cx->end();
+        }
+        // inverse column levels, innermost first; the outermost writes the caller's ab
+        for (int j = m - 1; j >= 0; --j) {
+            const Col64Args ca_ = j == 0 ? fill_col(pl, 0, true, w0, nullptr, cout, nullptr, L, ab_stride, L, out_len, true)
+                                         : fill_col(pl, j, true, w0, nullptr, w0, nullptr, L, L, L, L, false);
+            cx->begin(K_COL64);
+            (pl->level_log[j] >= 5 ? launch_col64x : launch_col64)(pl->level_log[j], true, false, ca_, pl->mp,
+                                                                   L >> pl->level_log[j], cb, 1, s);
+            cx->end();
+        }
     }
     HIP_TRY(hipGetLastError());
     return NTT_OK;
