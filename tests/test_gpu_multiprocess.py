@@ -69,6 +69,17 @@ def test_launcher_rank_layout(tmp_path, nttdata, world, backend):
     assert np.array_equal(np.loadtxt(out / "1.out", dtype=np.uint64).astype(np.uint32), nttdata[1][4])
     for cid, ab in expected.items():
         assert np.array_equal(np.loadtxt(out / f"{cid}.out", dtype=np.uint64), ab)
+    # packed cases through the same launcher (one configuration is enough: the loader runs on rank 0 only)
+    if (world, backend) == (2, "gloo"):
+        import ntt_amd
+        for cid in (0, 1, 2, 4):
+            ntt_amd.pack_case(data, cid)
+        r = subprocess.run(cmd + ["--bin"], env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 1 and "case 3 skipped" in r.stderr, r.stderr[-2000:]
+        assert r.stdout.count("多项式乘法结果正确") == 4 and "多项式乘法结果错误" not in r.stdout
+        n4, p4, _, _ = ntt_amd.read_case_bin(data, 4)
+        assert ntt_amd.check_case_bin(data, 4, expected[4]) and (n4, p4) == (3001, 1337006139375617)
+        assert (out / "4.outb").exists() and (out / "1.outb").exists()
     # a wrong expected output flips the verdict and the exit status
     (data / "3.in").write_text((data / "0.in").read_text())
     (data / "3.out").write_text("1 2 3 4 5 6 7 ")
