@@ -749,3 +749,40 @@ def test_binding_checks_shapes_before_launching(nt, ctx):
     with pytest.raises(ValueError):
         ctx.crt_multiply(np.ones(n, dtype=np.uint64), np.ones(n, dtype=np.uint64), 1337006139375617,
                          out=np.zeros(n, dtype=np.uint64))
+
+
+def test_caller_stream(nt):
+    """ntt_ctx_set_stream / ntt_ctx_stream: the library enqueues on a stream of the caller's (torch's) and is
+    then ordered with the caller's own work by the stream alone -- inputs produced by torch kernels just before
+    the call, the result consumed by a torch kernel just after, no synchronisation in between; with the
+    lanes' fork and join (a batch of several chunks) on the caller's stream as well."""
+    import torch
+    c = nt.Context(0)
+    own = c.stream
+    side = torch.cuda.Stream()
+    c.set_stream(side.cuda_stream)
+    assert c.stream == side.cuda_stream
+    n, p, B = 131072, 998244353, 6
+    rng = np.random.default_rng(8)
+    a, b = rand_poly(rng, n, p, B), rand_poly(rng, n, p, B)
+    import os
+    os.environ["NTT_AMD_CHUNK"] = "2"                           # three chunks, two lanes
+    try:
+        plan = c.plan(p, n, B)
+    finally:
+        del os.environ["NTT_AMD_CHUNK"]
+    ha, hb = torch.from_numpy(a.view(np.int32)), torch.from_numpy(b.view(np.int32))
+    with torch.cuda.stream(side):
+        da = ha.cuda(non_blocking=False) + 0                    # produced by a torch kernel on `side`
+        db = hb.cuda(non_blocking=False) + 0
+        out = torch.zeros((B, 2 * n - 1), dtype=torch.int32, device="cuda")
+        plan.multiply(da, db, out=out, batch=B)
+        res = out.clone()                                       # consumed on `side` right behind the library's kernels
+    side.synchronize()
+    got = res.cpu().numpy().view(np.uint32)
+    for r in range(B):
+        assert np.array_equal(got[r], orc.poly_multiply(a[r], b[r], p)), r
+    c.set_stream(0)                                             # back to the context's own stream
+    assert c.stream == own
+    plan.close()
+    c.close()
