@@ -203,8 +203,8 @@ static int build_tables(ntt_plan *pl)
         const bool innermost = (j == pl->nlevels - 1);
         if (pl->level_log[j] >= 5) {                     // inner twiddles of the LDS-staged column kernel
             const uint32_t wN = h_powmod(wL, L / N1, p), iwN = h_powmod(iwL, L / N1, p);
-            typename MM::tw_t f[64], b[64];
-            for (uint32_t r = 0; r < 4; ++r)
+            typename MM::tw_t f[128] = {}, b[128] = {};
+            for (uint32_t r = 0; r < std::max(4u, N1 / 16); ++r)
                 for (uint32_t ka = 0; ka < 16; ++ka) {
                     f[r * 16 + ka] = MM::make_tw(h_powmod(wN, (uint64_t)r * ka, p), mp);
                     b[r * 16 + ka] = MM::make_tw(h_powmod(iwN, (uint64_t)r * ka, p), mp);
@@ -264,7 +264,7 @@ static ColArgs<MM> fill_col(ntt_plan *pl, int level, bool inverse, const uint32_
     fill_roots<MM>(a.roots, inverse ? pl->iroots : pl->roots);
     if (pl->level_log[level] >= 5) {
         const auto &src = inverse ? pl->tw_in_inv[level] : pl->tw_in_fwd[level];
-        std::memcpy(a.tw_in, src.data(), sizeof(a.tw_in));
+        std::memcpy(a.tw_in, src.data(), std::min(src.size(), sizeof(a.tw_in)));
     }
     return a;
 }
@@ -279,7 +279,8 @@ static void col_pass(ntt_plan *pl, int level, bool inverse, bool half_in, const 
     ColArgs<MM> a = fill_col<MM>(pl, level, inverse, in0, in1, out0, out1, in_stride, out_stride, in_len,
                                  out_len, tw, use_scale0, scale0, canon, twist);
     ntt_ctx *cx = pl->ctx;
-    const bool col16 = (inverse ? pl->col16_inv : pl->col16_fwd) && pl->level_log[level] >= 5;
+    // 128 points exist only in the LDS-staged kernel; 32 and 64 in both
+    const bool col16 = pl->level_log[level] == 7 || ((inverse ? pl->col16_inv : pl->col16_fwd) && pl->level_log[level] >= 5);
     cx->begin(inverse ? K_COL_INV : K_COL_FWD);
     if (col16)
         launch_col16(pl->kind, pl->lazy, pl->level_log[level], inverse, half_in, &a, pl->mp,
