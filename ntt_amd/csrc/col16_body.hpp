@@ -8,15 +8,15 @@
 namespace ntt {
 
 // Body of the LDS-staged column pass for one tile: `bx` = tile index within the row (blockIdx.x
-// of the stand-alone kernel), `by` = batch row, `op` = operand.  `lds` holds N1 * C words (4096; 8192 for N1 = 128).
+// of the stand-alone kernel), `by` = batch row, `op` = operand.  `lds` holds N1 * C words (4096; 8192 / 16384 for N1 = 128 / 256).
 template <class MM, bool LAZY, int LOGR, bool INVERSE, bool HALF>
 __device__ __forceinline__ void col16_body(const ColArgs<MM> &a, const ModParams &m, uint32_t *lds,
                                            const uint32_t bx, const uint32_t by, const int op)
 {
     using O = Ops<MM, LAZY>;
     using tw_t = typename MM::tw_t;
-    constexpr int R = 1 << LOGR;             // 2, 4 or 8: N1 = 32, 64, 128 points
-    constexpr int LOGT = LOGR == 3 ? 9 : 8;  // 256 threads, 512 for N1 = 128 (64 columns keep r wave-uniform)
+    constexpr int R = 1 << LOGR;             // 2, 4, 8 or 16: N1 = 32, 64, 128, 256 points
+    constexpr int LOGT = LOGR <= 2 ? 8 : LOGR + 6;   // 256 threads; 512 / 1024 for N1 = 128 / 256 (64 columns keep r wave-uniform)
     constexpr int LOGC = LOGT - LOGR;        // columns per workgroup
     constexpr int C = 1 << LOGC;
     constexpr int KA = 16 / R;               // ka values per thread in pass 2

@@ -203,7 +203,7 @@ static int build_tables(ntt_plan *pl)
         const bool innermost = (j == pl->nlevels - 1);
         if (pl->level_log[j] >= 5) {                     // inner twiddles of the LDS-staged column kernel
             const uint32_t wN = h_powmod(wL, L / N1, p), iwN = h_powmod(iwL, L / N1, p);
-            typename MM::tw_t f[128] = {}, b[128] = {};
+            typename MM::tw_t f[256] = {}, b[256] = {};
             for (uint32_t r = 0; r < std::max(4u, N1 / 16); ++r)
                 for (uint32_t ka = 0; ka < 16; ++ka) {
                     f[r * 16 + ka] = MM::make_tw(h_powmod(wN, (uint64_t)r * ka, p), mp);
@@ -279,8 +279,8 @@ static void col_pass(ntt_plan *pl, int level, bool inverse, bool half_in, const 
     ColArgs<MM> a = fill_col<MM>(pl, level, inverse, in0, in1, out0, out1, in_stride, out_stride, in_len,
                                  out_len, tw, use_scale0, scale0, canon, twist);
     ntt_ctx *cx = pl->ctx;
-    // 128 points exist only in the LDS-staged kernel; 32 and 64 in both
-    const bool col16 = pl->level_log[level] == 7 || ((inverse ? pl->col16_inv : pl->col16_fwd) && pl->level_log[level] >= 5);
+    // 128 and 256 points exist only in the LDS-staged kernel; 32 and 64 in both
+    const bool col16 = pl->level_log[level] >= 7 || ((inverse ? pl->col16_inv : pl->col16_fwd) && pl->level_log[level] >= 5);
     cx->begin(inverse ? K_COL_INV : K_COL_FWD);
     if (col16)
         launch_col16(pl->kind, pl->lazy, pl->level_log[level], inverse, half_in, &a, pl->mp,
@@ -852,7 +852,11 @@ static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_ki
     }
     if (logL > kRowLog) {
         const int c = logL - kRowLog;
-        const int m = (c + kMaxColLog - 1) / kMaxColLog;
+        // 256-point levels pay for zero-padded (linear) products only: 10.4 vs 12.8 us at L = 2^20; with a
+        // full-length first level (negacyclic) two levels of 16 points are faster (14.5 vs 16.3 us)
+        int maxlog = negacyclic ? kMaxColLog - 1 : kMaxColLog;
+        if (const char *e = std::getenv("NTT_AMD_COL_MAXLOG")) maxlog = std::max(4, std::min(kMaxColLog, std::atoi(e)));
+        const int m = (c + maxlog - 1) / maxlog;
         int logM = logL;
         for (int j = 0; j < m; ++j) {
             pl->level_log[j] = c / m + (j < c % m ? 1 : 0);

@@ -11,7 +11,7 @@ namespace ntt {
 
 constexpr int kRowLog = 12;              // LDS-resident row transform: 4096 points
 constexpr int kRowLen = 1 << kRowLog;
-constexpr int kMaxColLog = 7;            // column level: up to 64 points in registers, 128 in the LDS-staged kernel
+constexpr int kMaxColLog = 8;            // column level: up to 64 points in registers, 128 / 256 in the LDS-staged kernel
 
 // w_64^j, j < 32 (forward) or w_64^-j (inverse), passed by value so they live in SGPRs.
 template <class MM>
@@ -33,7 +33,7 @@ struct ColArgs {
     int use_scale0;
     int canon;                           // 1: final pass, store canonical residues
     Roots64<MM> roots;
-    typename MM::tw_t tw_in[128];        // col16 kernels: inner twiddles w_N1^(+-r*ka), index r*16 + ka, r < N1/16
+    typename MM::tw_t tw_in[256];        // col16 kernels: inner twiddles w_N1^(+-r*ka), index r*16 + ka, r < N1/16
     // negacyclic products (x^n + 1): [L] table psi^(+-i); a forward pass multiplies its inputs by it,
     // the final inverse pass its outputs.  nullptr for the ordinary (cyclic) transform.
     const typename MM::tw_t *twist;

@@ -17,9 +17,9 @@
 namespace ntt {
 
 template <class MM, bool LAZY, int LOGR, bool INVERSE, bool HALF>
-__global__ void __launch_bounds__(LOGR == 3 ? 512 : 256) col16_kernel(const ColArgs<MM> a, const ModParams m)
+__global__ void __launch_bounds__(LOGR <= 2 ? 256 : 64 << LOGR) col16_kernel(const ColArgs<MM> a, const ModParams m)
 {
-    __shared__ uint32_t lds[LOGR == 3 ? 8192 : 4096];
+    __shared__ uint32_t lds[LOGR <= 2 ? 4096 : 1024 << LOGR];
     col16_body<MM, LAZY, LOGR, INVERSE, HALF>(a, m, lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
@@ -27,7 +27,7 @@ template <class MM, bool LAZY, int LOGR>
 static void launch_t(bool inverse, bool half_in, const ColArgs<MM> &a, const ModParams &mp, dim3 grid,
                      hipStream_t s)
 {
-    const dim3 block(LOGR == 3 ? 512 : 256);
+    const dim3 block(LOGR <= 2 ? 256 : 64 << LOGR);
     if (inverse)
         hipLaunchKernelGGL((col16_kernel<MM, LAZY, LOGR, true, false>), grid, block, 0, s, a, mp);
     else if (half_in)
@@ -40,7 +40,8 @@ template <class MM, bool LAZY>
 static void launch_l(int logN1, bool inverse, bool half_in, const ColArgs<MM> &a, const ModParams &mp,
                      unsigned cols_per_row, unsigned batch, unsigned nops, hipStream_t s)
 {
-    if (logN1 == 7) launch_t<MM, LAZY, 3>(inverse, half_in, a, mp, dim3(cols_per_row / 64, batch, nops), s);
+    if (logN1 == 8) launch_t<MM, LAZY, 4>(inverse, half_in, a, mp, dim3(cols_per_row / 64, batch, nops), s);
+    else if (logN1 == 7) launch_t<MM, LAZY, 3>(inverse, half_in, a, mp, dim3(cols_per_row / 64, batch, nops), s);
     else if (logN1 == 6) launch_t<MM, LAZY, 2>(inverse, half_in, a, mp, dim3(cols_per_row / 64, batch, nops), s);
     else launch_t<MM, LAZY, 1>(inverse, half_in, a, mp, dim3(cols_per_row / 128, batch, nops), s);
 }
