@@ -40,6 +40,7 @@ struct ntt_plan64 {
     std::vector<uint64_t> tw_in_fwd[8], tw_in_inv[8];         // per level of 32 / 64 points: w_N1^(+-r*ka)
     uint64_t scale = 0;                     // L^-1 * R (cancels the pointwise R^-1), Montgomery form
     bool negacyclic = false;                // products modulo x^n + 1: L = n, psi twist
+    bool fold2048 = false;                  // x^2048 + 1 through the linear product of L = 4096, folded at the store
     uint64_t *twist_fwd = nullptr, *twist_inv = nullptr, *small_itwist = nullptr;
     DeviceBuffer work0, work1, stage_a, stage_b, stage_out;
     std::vector<void *> owned;
@@ -148,7 +149,7 @@ int build_tables(ntt_plan64 *pl)
     const uint64_t invL = powmod(L % p, p - 2, p);
     const uint64_t scale = mulmod(invL, mp.r1, p);                  // L^-1 * R
     pl->scale = to_mont(scale, mp);
-    if (pl->negacyclic) {      // psi = g^((p-1)/2L), psi^2 = wL; row 1 of a 2-row power table is psi^i
+    if (pl->negacyclic && !pl->fold2048) {      // psi = g^((p-1)/2L), psi^2 = wL; row 1 of a 2-row power table is psi^i
         const uint64_t psi = powmod(pl->g, (p - 1) / (2ull * L), p), ipsi = powmod(psi, p - 2, p);
         int rc = upload(pl, power_table(psi, 2, L, 1, mp), &pl->twist_fwd);
         if (!rc) rc = upload(pl, power_table(ipsi, 2, L, 1, mp), &pl->twist_inv);
@@ -175,7 +176,7 @@ int build_tables(ntt_plan64 *pl)
         if (rc) return rc;
         if ((rc = upload(pl, iw, &pl->row_iw))) return rc;
     }
-    if (pl->nlevels == 0) return NTT_OK;
+    if (pl->nlevels == 0 && pl->logL != kRowLog) return NTT_OK;
     {   // 4096-point row kernel: pass twiddles w_4096^(k*t), w_256^(k*i) and their inverses
         const uint64_t w4096 = powmod(wL, L / kRowLen, p), iw4096 = powmod(iwL, L / kRowLen, p);
         const uint64_t w256 = powmod(w4096, 16, p), iw256 = powmod(iw4096, 16, p);
@@ -230,7 +231,7 @@ Col64Args fill_col(ntt_plan64 *pl, int level, bool inverse, const uint64_t *in0,
     a.canon = canon ? 1 : 0;
     a.ext_in = (!inverse && level == 0) ? 1 : 0;
     a.roots = inverse ? pl->iroots : pl->roots;
-    a.twist = (pl->negacyclic && level == 0) ? (inverse ? pl->twist_inv : pl->twist_fwd) : nullptr;
+    a.twist = (pl->negacyclic && !pl->fold2048 && level == 0) ? (inverse ? pl->twist_inv : pl->twist_fwd) : nullptr;
     if (pl->level_log[level] >= 5) {
         const auto &src = inverse ? pl->tw_in_inv[level] : pl->tw_in_fwd[level];
         std::memcpy(a.tw_in, src.data(), sizeof(a.tw_in));
@@ -242,10 +243,26 @@ Col64Args fill_col(ntt_plan64 *pl, int level, bool inverse, const uint64_t *in0,
 int multiply_device(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64_t *ab, size_t ab_stride, int batch)
 {
     ntt_ctx *cx = pl->ctx;
-    const bool neg = pl->negacyclic;
-    const uint32_t n = (uint32_t)pl->n, L = pl->L, out_len = neg ? n : 2 * n - 1;
+    const bool neg = pl->negacyclic && !pl->fold2048;
+    const uint32_t n = (uint32_t)pl->n, L = pl->L, out_len = pl->negacyclic ? n : 2 * n - 1;
     hipStream_t s = cx->stream;
     cx->cur = s;
+    if (pl->nlevels == 0 && pl->logL == kRowLog && pl->twA) {      // L = 4096: the row kernel does the whole product
+        Row64ProdArgs r{};
+        r.row.a = a; r.row.b = b; r.row.out = ab;
+        r.row.twA = pl->twA; r.row.twB = pl->twB; r.row.itwA = pl->itwA; r.row.itwB = pl->itwB;
+        r.row.roots = pl->roots; r.row.iroots = pl->iroots;
+        r.in_stride = n; r.out_stride = ab_stride;
+        r.in_len = n; r.out_len = out_len;
+        r.scale = pl->scale;
+        r.fold = pl->fold2048 ? 1 : 0;
+        if (neg) { r.twist = pl->twist_fwd; r.itwist = pl->small_itwist; }
+        cx->begin(K_LDS64);
+        launch_row64_product(r, pl->mp, (unsigned)batch, s);
+        cx->end();
+        HIP_TRY(hipGetLastError());
+        return NTT_OK;
+    }
     if (pl->nlevels == 0) {
         Lds64Args r{};
         r.a = a; r.b = b; r.out = ab;
@@ -334,7 +351,13 @@ static int plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, bool nega
         return fail(NTT_ERR_UNSUPPORTED, "ntt_plan64_create: p64 must be a prime below 2^62");
     int lg = 1;
     while ((1ull << lg) < 2ull * (uint64_t)n) ++lg;                // smallest power of two >= 2n, at least 2
+    // x^2048 + 1: the linear product of L = 4096 (no twist), coefficients i and i + 2048 subtracted at the store
+    const bool fold2048 = negacyclic && n == 2048 && (p64 - 1) % (1ull << kRowLog) == 0;
+    if (fold2048) negacyclic = false;                              // ... for the rest of the plan's construction
     if (negacyclic) --lg;                                          // x^n + 1: transform length n, 2n-th root psi
+    // a linear product of L = 2048 runs faster as one of L = 4096 in the row kernel than at its own length in the
+    // radix-2 LDS kernel (0.046 vs 0.054 us): pad further when the prime allows
+    if (!negacyclic && lg == kRowLog - 1 && (p64 - 1) % (1ull << kRowLog) == 0) lg = kRowLog;
     if ((p64 - 1) % (1ull << (negacyclic ? lg + 1 : lg)) != 0)
         return fail(NTT_ERR_UNSUPPORTED, "ntt_plan64_create: p64 - 1 is not divisible by the transform length");
     if ((uint64_t)batch << lg > (1ull << 29))
@@ -348,7 +371,8 @@ static int plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, bool nega
     pl->p = p64;
     pl->n = n;
     pl->batch = batch;
-    pl->negacyclic = negacyclic;
+    pl->negacyclic = negacyclic || fold2048;
+    pl->fold2048 = fold2048;
     pl->logL = lg;
     pl->L = 1u << lg;
     pl->mp = make_params(p64);

@@ -204,6 +204,17 @@ struct Row64Args {
     const uint64_t *itwA, *itwB;         // inverse
     Roots16x64 roots, iroots;
 };
+// A whole 64-bit product of transform length L = 4096 in the row kernel: zero padding, negacyclic twist, scale
+// and output cut included (the 64-bit counterpart of Row4096Args)
+struct Row64ProdArgs {
+    Row64Args row;                       // tables and roots; row.a / row.b / row.out = batch bases
+    size_t in_stride, out_stride;
+    uint32_t in_len, out_len;
+    uint64_t scale;                      // L^-1 (times R on the Montgomery lanes), table form
+    const uint64_t *twist, *itwist;      // negacyclic: psi^i, and psi^-i with the scale folded in
+    int fold;                            // 1: store c[i] = ab[i] - ab[i + 2048], i < 2048
+};
+void launch_row64_product(const Row64ProdArgs &a, const ModParams64 &mp, unsigned batch, hipStream_t s);
 void launch_fused_product(int kind, bool lazy, const void *args, const ModParams &mp,
                           unsigned batch, hipStream_t s);
 void launch_row64_mul(const Row64Args &a, const ModParams64 &mp, unsigned rows, hipStream_t s);

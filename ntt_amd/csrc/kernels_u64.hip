@@ -563,6 +563,63 @@ __global__ void __launch_bounds__(256) row64_mul_kernel(const Row64Args a, const
     for (int j = 0; j < 16; ++j) po[t + 256 * j] = A::bits(xa[j]);
 }
 
+// Whole product of one pair when L = 4096: the row kernel with the padding, twist, scale and output cut that
+// the column passes do for longer transforms (the radix-2 LDS kernel below takes 12 barrier-separated stages
+// per transform for the same work).
+template <class A>
+__global__ void __launch_bounds__(256) row64_product_kernel(const Row64ProdArgs a, const ModParams64 m)
+{
+    using T = typename A::T;
+    __shared__ uint64_t lds[kRow64Words];
+    const uint32_t t = threadIdx.x;
+    const uint64_t *__restrict__ pa = a.row.a + (size_t)blockIdx.x * a.in_stride;
+    const uint64_t *__restrict__ pb = a.row.b + (size_t)blockIdx.x * a.in_stride;
+    T xa[16], xb[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t i = t + 256u * j;
+        xa[j] = i < a.in_len ? A::ext_in(pa[i], m) : A::zero();
+        xb[j] = i < a.in_len ? A::ext_in(pb[i], m) : A::zero();
+    }
+    if (a.twist) {                                            // negacyclic: operands times psi^i (uniform)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const T w = A::raw(a.twist[t + 256u * j]);
+            xa[j] = A::mulw(xa[j], w, m);
+            xb[j] = A::mulw(xb[j], w, m);
+        }
+    }
+    row64_forward<A>(xa, lds, t, a.row, m);
+    row64_forward<A>(xb, lds, t, a.row, m);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) xa[k] = A::mulw(xa[k], xb[k], m);
+    row64_inverse<A>(xa, lds, t, a.row, m);
+    uint64_t *__restrict__ po = a.row.out + (size_t)blockIdx.x * a.out_stride;
+    if (a.fold) {                                             // x^2048 + 1: position i + 2048 sits in the same thread (uniform)
+        const T w = A::raw(a.scale);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t i = t + 256u * j;
+            const T d = A::sub(A::mulw(xa[j], w, m), A::mulw(xa[j + 8], w, m), m);
+            if (i < a.out_len) po[i] = A::canon_bits(d, m);
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t i = t + 256u * j;
+        const T w = A::raw(a.itwist ? a.itwist[i] : a.scale);
+        if (i < a.out_len) po[i] = A::canon_bits(A::mulw(xa[j], w, m), m);
+    }
+}
+
+void launch_row64_product(const Row64ProdArgs &a, const ModParams64 &mp, unsigned batch, hipStream_t s)
+{
+    NTT_U64_DISPATCH(mp, hipLaunchKernelGGL(row64_product_kernel<M64>, dim3(batch), dim3(256), 0, s, a, mp),
+                     hipLaunchKernelGGL(row64_product_kernel<F64>, dim3(batch), dim3(256), 0, s, a, mp),
+                     hipLaunchKernelGGL(row64_product_kernel<F64L>, dim3(batch), dim3(256), 0, s, a, mp));
+}
+
 void launch_row64_mul(const Row64Args &a, const ModParams64 &mp, unsigned rows, hipStream_t s)
 {
     NTT_U64_DISPATCH(mp, hipLaunchKernelGGL(row64_mul_kernel<M64>, dim3(rows), dim3(256), 0, s, a, mp),

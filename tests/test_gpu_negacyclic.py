@@ -189,7 +189,7 @@ def fold(ab, n, p):
     return np.array([(ab[i] - (ab[i + n] if i + n < len(ab) else 0)) % p for i in range(n)], dtype=np.uint64)
 
 
-@pytest.mark.parametrize("n", [2, 8, 256, 4096, 8192, 65536, 131072])
+@pytest.mark.parametrize("n", [2, 8, 256, 1024, 2048, 4096, 8192, 65536, 131072])
 @pytest.mark.parametrize("p", [P51, 1125899437080577])          # the reference's 51-bit prime, and one just below 2^50
 def test_negacyclic64_vs_linear_crt_oracle(ctx, n, p, lanes64):
     """Small block (L <= 4096), one column level, two levels; against the 4-prime CRT oracle's linear product."""
