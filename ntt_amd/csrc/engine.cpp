@@ -878,8 +878,17 @@ static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_ki
         size_t per = (size_t)L * sizeof(uint32_t);
         long chunk = (long)((96u << 20) / (2 * per));
         if (const char *e = std::getenv("NTT_AMD_CHUNK")) chunk = std::atol(e);
+        const bool chunk_forced = std::getenv("NTT_AMD_CHUNK") != nullptr;
         chunk = std::max<long>(1, std::min<long>(chunk, batch));
         chunk = std::min<long>(chunk, 65535);
+        // a few chunks only: equal shares, so that the last launch is not a small one (64 products: 32 + 32
+        // instead of 48 + 16, 14.3 -> 13.6 us per CRT product); with many chunks the tail does not matter and
+        // full-size chunks measured 1.5 % better
+        if (!chunk_forced) {
+            long nch = (batch + chunk - 1) / chunk;
+            if (nch > 1 && nch <= 4 && (nch & 1) && ctx->nlanes == 2) ++nch;     // the same number of chunks on both lanes
+            if (nch <= 4) chunk = (batch + nch - 1) / nch;
+        }
         pl->chunk = (int)chunk;
         pl->lanes = (int)std::min<long>(ctx->nlanes, (batch + chunk - 1) / chunk);
         // Off by default: measured on MI355X the fused launch only matches the three separate
