@@ -349,6 +349,12 @@ static void row_pass(ntt_plan *pl, int which, const uint32_t *a0, const uint32_t
 {
     RowArgs<MM> a = fill_row<MM>(pl, a0, b0, out);
     ntt_ctx *cx = pl->ctx;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    static const bool ext_events = [] { const char *e = std::getenv("NTT_AMD_EXT_EVENTS"); return !(e && e[0] == '0'); }();
+    if (which == 0 && ext_events && cx->begin_ext(K_ROW_MUL, &e0, &e1)) {
+        launch_row_mul_timed(pl->kind, pl->lazy, &a, pl->mp, rows, cx->cur, e0, e1);
+        return;
+    }
     cx->begin(which == 0 ? K_ROW_MUL : which == 1 ? K_ROW_FWD : K_ROW_INV);
     if (which == 0) launch_row_mul(pl->kind, pl->lazy, &a, pl->mp, rows, cx->cur);
     else if (which == 1) launch_row_fwd(pl->kind, pl->lazy, &a, pl->mp, rows, cx->cur);
@@ -628,6 +634,21 @@ void ntt_ctx::begin(int id)
         return;
     }
     stamps.push_back(s);
+}
+bool ntt_ctx::begin_ext(int id, hipEvent_t *e0, hipEvent_t *e1)
+{
+    stamp_open = false;
+    if (!(timing && (timing_only < 0 || timing_only == id))) return false;
+    Stamp s{id, grab_event(), grab_event()};
+    if (!s.e0 || !s.e1) {
+        if (s.e0) event_pool.push_back(s.e0);
+        if (s.e1) event_pool.push_back(s.e1);
+        return false;
+    }
+    stamps.push_back(s);
+    *e0 = s.e0;
+    *e1 = s.e1;
+    return true;
 }
 void ntt_ctx::end()
 {

@@ -78,6 +78,8 @@ struct ntt_ctx {
     long acc_n[ntt::K_COUNT] = {0};
     void begin(int id);
     void end();
+    // for launches that carry their own start / stop events: true (and the pair) when this launch is to be timed
+    bool begin_ext(int id, hipEvent_t *e0, hipEvent_t *e1);
     int fold();                                       // sync + accumulate + recycle events
     hipEvent_t grab_event();
 

@@ -114,6 +114,10 @@ void launch_col16(int kind, bool lazy, int logN1, bool inverse, bool half_in, co
 void launch_pipe(int kind, bool lazy, int logN1, const void *args, const ModParams &mp, unsigned groups,
                  hipStream_t s);
 void launch_row_mul(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);
+// the same launch with the kernel's own start / stop events (hipExtLaunchKernelGGL): kernel timing without the
+// extra queue packets of hipEventRecord around it
+void launch_row_mul_timed(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s,
+                          hipEvent_t start, hipEvent_t stop);
 // L = 4096 exactly: the whole product of one pair in the row kernel (args: Row4096Args<MM>)
 void launch_row_product(int kind, bool lazy, const void *args, const ModParams &mp, unsigned batch, hipStream_t s);
 void launch_row_fwd(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);

@@ -13,6 +13,8 @@
 // row_mul_kernel fuses: forward(a row), forward(b row), pointwise product
 // (main-montgomery.cc:341-344) and the inverse row transform -- the 12 small-stride stages of
 // three NTT_iterative calls plus the pointwise loop in one read of a, b and one write.
+#include <hip/hip_ext.h>
+
 #include "row_body.hpp"
 
 namespace ntt {
@@ -145,6 +147,21 @@ static void launch_row_any(int kind, bool lazy, const void *args, const ModParam
         if (lazy) launch_row_t<WHICH, Barrett32, true>(a, mp, rows, s);
         else launch_row_t<WHICH, Barrett32, false>(a, mp, rows, s);
     }
+}
+
+template <class MM>
+static void launch_row_mul_ext(bool lazy, const RowArgs<MM> &a, const ModParams &mp, unsigned rows, hipStream_t s,
+                               hipEvent_t e0, hipEvent_t e1)
+{
+    if (lazy) hipExtLaunchKernelGGL((row_mul_kernel<MM, true>), dim3(rows), dim3(256), 0, s, e0, e1, 0, a, mp);
+    else hipExtLaunchKernelGGL((row_mul_kernel<MM, false>), dim3(rows), dim3(256), 0, s, e0, e1, 0, a, mp);
+}
+
+void launch_row_mul_timed(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s,
+                          hipEvent_t start, hipEvent_t stop)
+{
+    if (kind == 0) launch_row_mul_ext<Mont32>(lazy, *static_cast<const RowArgs<Mont32> *>(args), mp, rows, s, start, stop);
+    else launch_row_mul_ext<Barrett32>(lazy, *static_cast<const RowArgs<Barrett32> *>(args), mp, rows, s, start, stop);
 }
 
 void launch_row_mul(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s)
