@@ -189,7 +189,18 @@ struct Barrett32 {
     static NTT_HD uint32_t mul_tw(uint32_t x, tw_t t, const ModParams &m)
     {
         uint32_t q = mulhi32(x, t.wq);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTT_NO_MADI64)
+        // x*w - q*p mod 2^32 as one multiply-add: q * (2^32 - p) + low(x*w) is the low word of v_mad_u64_u32
+        // (hipcc folds the C++ form back into multiply + subtract; ask for the one instruction)
+        // (the addend is the full 64-bit x*w: its high word does not reach the low word of the result, and
+        // taking it along saves the zero-extension of a 32-bit addend)
+        uint64_t T, carry;
+        const uint64_t addend = (uint64_t)x * t.w;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(T), "=s"(carry) : "v"(q), "s"(0u - m.p), "v"(addend));
+        return (uint32_t)T;
+#else
         return x * t.w - q * m.p;                      // exact mod 2^32, value in [0, 2p)
+#endif
     }
     static NTT_HD uint32_t mul_tw_diff(uint32_t u, uint32_t v, tw_t t, uint32_t bound, const ModParams &m)
     {
