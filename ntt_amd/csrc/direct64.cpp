@@ -200,9 +200,9 @@ int build_tables(ntt_plan64 *pl)
         const bool innermost = (j == pl->nlevels - 1);
         if (pl->level_log[j] >= 5) {                     // inner twiddles of the LDS-staged level
             const uint64_t wN = powmod(wL, L / N1, p), iwN = powmod(iwL, L / N1, p);
-            pl->tw_in_fwd[j].assign(64, 0);
-            pl->tw_in_inv[j].assign(64, 0);
-            for (uint32_t r = 0; r < 4; ++r)
+            pl->tw_in_fwd[j].assign(128, 0);
+            pl->tw_in_inv[j].assign(128, 0);
+            for (uint32_t r = 0; r < std::max(4u, N1 / 16); ++r)
                 for (uint32_t ka = 0; ka < 16; ++ka) {
                     pl->tw_in_fwd[j][r * 16 + ka] = to_mont(powmod(wN, (uint64_t)r * ka, p), mp);
                     pl->tw_in_inv[j][r * 16 + ka] = to_mont(powmod(iwN, (uint64_t)r * ka, p), mp);
@@ -384,8 +384,8 @@ static int plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, bool nega
     if (lg > kRowLog) {
         // column levels of at most 64 points: 5 or 6 bits go through the LDS-staged kernel (one pass over
         // memory), up to 4 bits through the register kernel
-        int maxlog = 6;
-        if (const char *e = std::getenv("NTT_AMD_COL64_MAXLOG")) maxlog = std::max(1, std::min(6, std::atoi(e)));
+        int maxlog = 7;
+        if (const char *e = std::getenv("NTT_AMD_COL64_MAXLOG")) maxlog = std::max(1, std::min(7, std::atoi(e)));
         const int c = lg - kRowLog, m = (c + maxlog - 1) / maxlog;
         int logM = lg;
         for (int j = 0; j < m; ++j) {

@@ -186,7 +186,7 @@ struct Col64Args {
     int ext_in;                          // input is the caller's (u64 residues < p), not an intermediate
     Roots16x64 roots;
     const uint64_t *twist;               // negacyclic: [L] psi^(+-i), Montgomery form; nullptr otherwise
-    uint64_t tw_in[64];                  // LDS-staged levels of 32 / 64 points: w_N1^(+-r*ka), index r*16 + ka
+    uint64_t tw_in[128];                 // LDS-staged levels of 32 / 64 / 128 points: w_N1^(+-r*ka), index r*16 + ka
 };
 struct Lds64Args {
     const uint64_t *a, *b;

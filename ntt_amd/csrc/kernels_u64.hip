@@ -272,14 +272,15 @@ void launch_col64(int logN1, bool inverse, bool half_in, const Col64Args &a, con
 // its ka and applies the 4-step twiddle.  One pass over memory for 5 or 6 bits of the transform length
 // where the register kernel above needs two (64 points of 64 bits do not fit a thread: 404-512 VGPRs).
 template <class A, int LOGR, bool INVERSE, bool HALF>
-__global__ void __launch_bounds__(256) col64x_kernel(const Col64Args a, const ModParams64 m)
+__global__ void __launch_bounds__(LOGR <= 2 ? 256 : 64 << LOGR) col64x_kernel(const Col64Args a, const ModParams64 m)
 {
     using T = typename A::T;
     constexpr int R = 1 << LOGR;
-    constexpr int LOGC = 8 - LOGR;
+    constexpr int LOGT = LOGR <= 2 ? 8 : LOGR + 6;        // 256 threads; 512 for N1 = 128 (64 columns keep r wave-uniform)
+    constexpr int LOGC = LOGT - LOGR;
     constexpr int C = 1 << LOGC;
     constexpr int KA = 16 / R;
-    __shared__ uint64_t lds[4096];
+    __shared__ uint64_t lds[LOGR <= 2 ? 4096 : 1024 << LOGR];
     const uint32_t tid = threadIdx.x;
     const uint32_t cl = tid & (C - 1);
     const int r = __builtin_amdgcn_readfirstlane(tid >> LOGC);        // wave-uniform
@@ -354,16 +355,21 @@ __global__ void __launch_bounds__(256) col64x_kernel(const Col64Args a, const Mo
 template <class A, int LOGR>
 static void launch_col64x_t(bool inverse, bool half_in, const Col64Args &a, const ModParams64 &mp, dim3 grid, hipStream_t s)
 {
-    if (inverse) hipLaunchKernelGGL((col64x_kernel<A, LOGR, true, false>), grid, dim3(256), 0, s, a, mp);
-    else if (half_in) hipLaunchKernelGGL((col64x_kernel<A, LOGR, false, true>), grid, dim3(256), 0, s, a, mp);
-    else hipLaunchKernelGGL((col64x_kernel<A, LOGR, false, false>), grid, dim3(256), 0, s, a, mp);
+    const dim3 block(LOGR <= 2 ? 256 : 64 << LOGR);
+    if (inverse) hipLaunchKernelGGL((col64x_kernel<A, LOGR, true, false>), grid, block, 0, s, a, mp);
+    else if (half_in) hipLaunchKernelGGL((col64x_kernel<A, LOGR, false, true>), grid, block, 0, s, a, mp);
+    else hipLaunchKernelGGL((col64x_kernel<A, LOGR, false, false>), grid, block, 0, s, a, mp);
 }
 
 void launch_col64x(int logN1, bool inverse, bool half_in, const Col64Args &a, const ModParams64 &mp,
                    unsigned cols_per_row, unsigned batch, unsigned nops, hipStream_t s)
 {
-    const dim3 grid(cols_per_row / (logN1 == 6 ? 64 : 128), batch, nops);
-    if (logN1 == 6) {
+    const dim3 grid(cols_per_row / (logN1 == 5 ? 128 : 64), batch, nops);
+    if (logN1 == 7) {
+        NTT_U64_DISPATCH(mp, (launch_col64x_t<M64, 3>(inverse, half_in, a, mp, grid, s)),
+                         (launch_col64x_t<F64, 3>(inverse, half_in, a, mp, grid, s)),
+                         (launch_col64x_t<F64L, 3>(inverse, half_in, a, mp, grid, s)));
+    } else if (logN1 == 6) {
         NTT_U64_DISPATCH(mp, (launch_col64x_t<M64, 2>(inverse, half_in, a, mp, grid, s)),
                          (launch_col64x_t<F64, 2>(inverse, half_in, a, mp, grid, s)),
                          (launch_col64x_t<F64L, 2>(inverse, half_in, a, mp, grid, s)));

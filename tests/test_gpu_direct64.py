@@ -142,7 +142,8 @@ def test_direct64_evaluation_identity(ctx, p, n):
         assert horner(a, x, p) * horner(b, x, p) % p == horner(ab, x, p), x
 
 
-@pytest.mark.parametrize("p,n", [(P51, (1 << 19) + 3), (P51, 1 << 22), (P62, 1 << 21), (P51B, 1 << 20)])
+@pytest.mark.parametrize("p,n", [(P51, 200000), (P62, 1 << 18), (P50, 150001),          # L = 2^19: one level of 128 points
+                                 (P51, (1 << 19) + 3), (P51, 1 << 22), (P62, 1 << 21), (P51B, 1 << 20)])
 def test_direct64_large_sizes(ctx, p, n):
     """Two and three column levels in front of the rows (L = 2^21 ... 2^23; the plan limit is n = 2^23):
     beyond the CRT oracle's exactness bound, so checked through A(x) * B(x) = AB(x) at x = 1, -1 (sums)
