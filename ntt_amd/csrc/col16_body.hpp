@@ -96,7 +96,8 @@ __device__ __forceinline__ void col16_body(const ColArgs<MM> &a, const ModParams
                     else
                         v = O::canon(O::tighten(v, m), m);
                 }
-                buf_store(v, rout, voff + (row << rowsh), 0);
+                if constexpr (CANON && INVERSE) buf_store_nt(v, rout, voff + (row << rowsh), 0);
+                else buf_store(v, rout, voff + (row << rowsh), 0);
             }
         }
     };

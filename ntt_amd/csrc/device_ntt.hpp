@@ -87,6 +87,19 @@ __device__ __forceinline__ void buf_store(uint32_t v, bufrsrc_t r, uint32_t voff
 {
     __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, 0);
 }
+// streaming variants (cache policy NT): the caller's operands are read once and its result is never read back,
+// so they need not displace the intermediates that the next pass re-reads from L2 / Infinity Cache
+#ifndef NTT_NT_AUX
+#define NTT_NT_AUX 2
+#endif
+__device__ __forceinline__ uint32_t buf_load_nt(bufrsrc_t r, uint32_t voff, uint32_t soff)
+{
+    return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, NTT_NT_AUX);
+}
+__device__ __forceinline__ void buf_store_nt(uint32_t v, bufrsrc_t r, uint32_t voff, uint32_t soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, NTT_NT_AUX);
+}
 // twiddle table entry (4 B Montgomery, 8 B Barrett)
 template <class TW>
 __device__ __forceinline__ TW buf_load_tw(bufrsrc_t r, uint32_t voff, uint32_t soff)

@@ -39,7 +39,8 @@ __global__ void __launch_bounds__(256) col_kernel(const ColArgs<MM> a, const Mod
 #pragma unroll
     for (int i1 = 0; i1 < N1; ++i1) {
         if (HALF && i1 >= N1 / 2) x[i1] = 0;
-        else x[i1] = buf_load(rin, voff + ((uint32_t)i1 << rowsh), 0);
+        else x[i1] = (!INVERSE && HALF) ? buf_load_nt(rin, voff + ((uint32_t)i1 << rowsh), 0)
+                                        : buf_load(rin, voff + ((uint32_t)i1 << rowsh), 0);
     }
     if (!INVERSE && a.twist) {                                    // negacyclic: x[i] * psi^i  (uniform branch)
         const bufrsrc_t rtwist = make_buf(a.twist, (uint32_t)sizeof(tw_t) << a.logM);

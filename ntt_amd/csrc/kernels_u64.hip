@@ -231,7 +231,10 @@ __global__ void __launch_bounds__(256) col64_kernel(const Col64Args a, const Mod
         const uint32_t idx = base + ((uint32_t)k1 << a.logS);
         T v = x[k1];
         if (INVERSE && a.canon && a.twist) v = A::mulw(v, A::raw(a.twist[idx]), m);      // negacyclic: result * psi^-i
-        if (idx < a.out_len) out[idx] = a.canon ? A::canon_bits(v, m) : A::bits(v);
+        if (idx < a.out_len) {
+            if (a.canon) __builtin_nontemporal_store(A::canon_bits(v, m), out + idx);          // the caller's: not read back
+            else out[idx] = A::bits(v);
+        }
     }
 }
 
@@ -347,7 +350,10 @@ __global__ void __launch_bounds__(LOGR <= 2 ? 256 : 64 << LOGR) col64x_kernel(co
             } else {
                 if (a.canon && a.twist) v = A::mulw(v, A::raw(a.twist[idx]), m);        // negacyclic: result * psi^-i
             }
-            if (idx < a.out_len) out[idx] = a.canon ? A::canon_bits(v, m) : A::bits(v);
+            if (idx < a.out_len) {
+                if (a.canon) __builtin_nontemporal_store(A::canon_bits(v, m), out + idx);      // the caller's: not read back
+                else out[idx] = A::bits(v);
+            }
         }
     }
 }
