@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) col_kernel(const ColArgs<MM> a, const Mod
 #pragma unroll
     for (int i1 = 0; i1 < N1; ++i1) {
         if (HALF && i1 >= N1 / 2) x[i1] = 0;
-        else x[i1] = (!INVERSE && HALF) ? buf_load_nt(rin, voff + ((uint32_t)i1 << rowsh), 0)
+        else x[i1] = (!INVERSE && HALF) ? buf_load_nt(rin, voff + ((uint32_t)i1 << rowsh), 0)     // the caller's operand
                                         : buf_load(rin, voff + ((uint32_t)i1 << rowsh), 0);
     }
     if (!INVERSE && a.twist) {                                    // negacyclic: x[i] * psi^i  (uniform branch)
@@ -71,12 +71,12 @@ __global__ void __launch_bounds__(256) col_kernel(const ColArgs<MM> a, const Mod
         const uint32_t toff = base * (uint32_t)sizeof(tw_t);
 #pragma unroll
         for (int k1 = 0; k1 < N1; ++k1)
-            buf_store(O::canon(O::mul_tw(x[k1], buf_load_tw<tw_t>(rtwist, toff, (uint32_t)k1 << twsh), m), m), rout,
-                      voff + ((uint32_t)k1 << rowsh), 0);
+            buf_store_nt(O::canon(O::mul_tw(x[k1], buf_load_tw<tw_t>(rtwist, toff, (uint32_t)k1 << twsh), m), m), rout,
+                         voff + ((uint32_t)k1 << rowsh), 0);
     } else if (a.canon) {
 #pragma unroll
         for (int k1 = 0; k1 < N1; ++k1)
-            buf_store(O::canon(INVERSE ? O::tighten(x[k1], m) : x[k1], m), rout, voff + ((uint32_t)k1 << rowsh), 0);
+            buf_store_nt(O::canon(INVERSE ? O::tighten(x[k1], m) : x[k1], m), rout, voff + ((uint32_t)k1 << rowsh), 0);
     } else {
 #pragma unroll
         for (int k1 = 0; k1 < N1; ++k1) buf_store(x[k1], rout, voff + ((uint32_t)k1 << rowsh), 0);

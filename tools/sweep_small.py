@@ -4,7 +4,7 @@ import numpy as np, torch, ntt_amd
 ctx = ntt_amd.Context(0)
 p = 469762049
 rng = np.random.default_rng(0)
-for lgn in (11, 12, 13, 14):
+for lgn in (12, 13, 14, 15):
     n = 1 << lgn
     B = 4096 if lgn <= 13 else 2048
     a = torch.from_numpy(rng.integers(0, p, size=(B, n), dtype=np.int64).astype(np.int32)).cuda()
