@@ -43,7 +43,8 @@ __device__ __forceinline__ void col16_body(const ColArgs<MM> &a, const ModParams
             x[j] = 0;
         } else {
             const uint32_t row = (uint32_t)(R * j + r);                // wave-uniform
-            uint32_t v = buf_load(rin, voff + (row << rowsh), 0);
+            // HALF marks the first forward level of a linear product: the caller's operand, read once
+            uint32_t v = HALF ? buf_load_nt(rin, voff + (row << rowsh), 0) : buf_load(rin, voff + (row << rowsh), 0);
             if (!INVERSE && a.twist)                                   // negacyclic: x[i] * psi^i (uniform)
                 v = O::mul_tw(v, buf_load_tw<tw_t>(make_buf(a.twist, (uint32_t)sizeof(tw_t) << a.logM),
                                                    base * (uint32_t)sizeof(tw_t), row << twsh), m);
