@@ -7,17 +7,31 @@ resident in HBM.  With N GPUs every rank runs its own batch (independent units, 
 collective: "weak" scaling); the barrier and the max-over-ranks time go through torch.distributed
 (RCCL when N > 1).
 
+`python bench.py --gpus N` starts its N ranks itself when it is not already running under
+torch.distributed.run (WORLD_SIZE unset): it launches `python -m torch.distributed.run
+--nproc-per-node N bench.py ...` as a CHILD process before anything has touched the GPU, forwards
+the child's output and exits with its status -- the way the reference's distributed program brings
+up its own ranks (main-mpi.cc:642-665).  A rank whose torch.distributed world differs from --gpus
+exits non-zero.
+
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
   roofline     -- HBM roofline of the dominant kernel, timed with HIP events inside the library on
-                  the stream the kernels run on (ntt_ctx_enable_kernel_timing)
+                  the stream the kernels run on (ntt_ctx_enable_kernel_timing); `valu` = the integer
+                  VALU roofline beside it (the bound DESIGN.md section 5 argues), `kernels_one_lane`
+                  = per-kernel time on one stream lane (uncontended), `sustained` = the same step
+                  loop over >= 2 s after the timed region (board power settled)
   cpu_baseline -- the CPU oracle's restatement of the reference's OpenMP path (main-openmp.cc) timed
                   on this box's host cores on a bounded sample of the same workload (rank 0, N = 1);
                   this leg is the only place the oracle is touched: it also compares its product of
-                  pair 0 with the GPU's.  Every rank checks A(x) * B(x) = AB(x) on its own output first.
+                  pair 0 with the GPU's.  Every rank checks A(x) * B(x) = AB(x) on rows of its own
+                  output first.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,6 +42,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+# MI355X_MICROARCH.md "Wave scheduling": 256 CUs x 4 SIMD-32 at 2.4 GHz; a wave64 VALU instruction
+# issues over 2 cycles (v_add/v_sub/logic) or 4 (v_mul_lo/hi, v_mad_u64_u32, v_min, shifts:
+# profiles/ubench_intmul_r01.txt, ubench_valu2_r01.txt)
+SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
 
 
 def splitmix64(seed, count):
@@ -56,49 +74,99 @@ def evaluation_identity(a, b, ab, p, points=(1, 3, 0x2545F491)):
     return int(ab.max()) < p and all(horner(a, x % p) * horner(b, x % p) % p == horner(ab, x % p) for x in points)
 
 
-def cpu_baseline(n, p, threads, budget_s, gpu_row0):
+def usable_cores():
+    """(cores this process may run on, what limits them, CPUs the machine reports).  On the GPU boxes
+    os.cpu_count() is the whole machine; the job's share is what the affinity mask, the cgroup quota
+    and the OMP_NUM_THREADS the box exports allow."""
+    total = os.cpu_count() or 1
+    limits = {"os.cpu_count": total}
+    try:
+        limits["sched_getaffinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            limits["cgroup cpu.max"] = max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+    env = os.environ.get("OMP_NUM_THREADS", "")
+    if env.isdigit() and int(env) > 0:
+        limits["OMP_NUM_THREADS"] = int(env)
+    name = min(limits, key=lambda k: limits[k])
+    return limits[name], name, total
+
+
+def cpu_baseline(n, p, budget_s, gpu_row0):
     """The oracle's port of main-openmp.cc (per-stage block-parallel radix-2 NTT, 64-bit Montgomery),
     timed between the reference's Start/End stamps.  Checker code used as the reported baseline only;
-    its product of pair 0 (the same seeds as row 0 of rank 0's batch) is also compared with the GPU's."""
+    its product of pair 0 (the same seeds as row 0 of rank 0's batch) is also compared with the GPU's.
+    Reported at every core this job may use (SURVEY 8d ii) and at the reference's own num_threads(8)."""
     import orc
+    cores, limited_by, machine = usable_cores()
     a = (splitmix64(0x20250711, n) % np.uint64(p)).astype(np.uint64)
     b = (splitmix64(0x20250711 + (1 << 20), n) % np.uint64(p)).astype(np.uint64)
-    want, _ = orc.poly_multiply_omp(a, b, p, threads=threads)          # warm-up
+    want, _ = orc.poly_multiply_omp(a, b, p, threads=cores)          # warm-up
     if gpu_row0 is not None and not np.array_equal(np.asarray(want).astype(np.uint64), gpu_row0.astype(np.uint64)):
         print("bench: GPU result differs from the oracle", file=sys.stderr)
         sys.exit(1)
-    t0 = time.time()
-    secs, reps = 0.0, 0
-    while time.time() - t0 < budget_s and reps < 200:
-        _, s = orc.poly_multiply_omp(a, b, p, threads=threads)
-        secs += s
-        reps += 1
-    out = {"value": reps / secs, "unit": "poly-mults/s", "cores": threads, "kind": "port",
+
+    def timed(threads, budget, cap):
+        orc.poly_multiply_omp(a, b, p, threads=threads)
+        t0, secs, reps = time.time(), 0.0, 0
+        while time.time() - t0 < budget and reps < cap:
+            _, s = orc.poly_multiply_omp(a, b, p, threads=threads)
+            secs += s
+            reps += 1
+        return secs / reps, reps
+
+    per, reps = timed(cores, budget_s * 0.6, 200)
+    out = {"value": 1.0 / per, "unit": "poly-mults/s", "cores": cores, "kind": "port",
            "sample": f"{reps} products of n={n}, p={p} (oracle port of main-openmp.cc:678-692, "
-                     f"timer between its Start/End stamps), {threads} OpenMP threads",
-           "ms_per_product": 1e3 * secs / reps}
-    # SURVEY 8(d): also the reference's own hard-coded num_threads(8) and the single-thread
-    # Montgomery / Barrett harness bodies (main-montgomery.cc:317-351, main-barrett.cc:249-282); a few
-    # products each, whole call timed
+                     f"timer between its Start/End stamps), {cores} OpenMP threads = every core this job may use "
+                     f"(limited by {limited_by}; the machine reports {machine} CPUs)",
+           "ms_per_product": 1e3 * per, "machine_cpus": machine, "cores_limited_by": limited_by}
+    t8 = min(8, cores)
+    per8, reps8 = timed(t8, budget_s * 0.25, 100)
+    out["reference_threads"] = {"threads": t8, "value": 1.0 / per8, "ms_per_product": 1e3 * per8, "products": reps8,
+                                "note": "main-openmp.cc hard-codes num_threads(8) (:397)"}
+    # single-thread Montgomery / Barrett harness bodies (main-montgomery.cc:317-351, main-barrett.cc:249-282),
+    # a few products each, whole call timed
     others = {}
-    s8, r8 = 0.0, 0
-    for _ in range(10):
-        _, s = orc.poly_multiply_omp(a, b, p, threads=min(8, threads))
-        s8 += s
-        r8 += 1
-    others[f"openmp_{min(8, threads)}_threads_ms"] = 1e3 * s8 / r8
     a32, b32 = a.astype(np.uint32), b.astype(np.uint32)
     for kind in ("mont", "barrett"):
         orc.poly_multiply(a32, b32, p, kind=kind)
         t1 = time.time()
-        for _ in range(3):
+        for _ in range(2):
             orc.poly_multiply(a32, b32, p, kind=kind)
-        others[f"single_thread_{kind}_ms"] = 1e3 * (time.time() - t1) / 3
+        others[f"single_thread_{kind}_ms"] = 1e3 * (time.time() - t1) / 2
+    if orc.have_ref() and p < (1 << 31):
+        # the reference's own main-baseline.cc multiply body, compiled in place (oracle/_ref, kind "reference")
+        ia, ib = a32.view(np.int32).copy(), b32.view(np.int32).copy()
+        iab = np.zeros(2 * n - 1, dtype=np.int32)
+        orc.ref().ref_poly_multiply_ntt(ia, ib, iab, n, int(p))
+        t1 = time.time()
+        orc.ref().ref_poly_multiply_ntt(ia, ib, iab, n, int(p))
+        others["reference_main_baseline_cc_single_thread_ms"] = 1e3 * (time.time() - t1)
+        if gpu_row0 is not None and not np.array_equal(iab.view(np.uint32), gpu_row0):
+            print("bench: GPU result differs from the compiled reference (main-baseline.cc)", file=sys.stderr)
+            sys.exit(1)
     out["others_ms_per_product"] = others
     return out
 
 
-def main():
+def kernel_source_stamp():
+    """sha256 over the kernel sources: profiles/*.json carry the stamp of the build they were measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ntt_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -107,7 +175,7 @@ def main():
     ap.add_argument("--n", type=int, default=131072)
     ap.add_argument("--p", type=int, default=998244353)
     ap.add_argument("--barrett", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=14.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=0, help="products per kernel launch (0 = library default)")
     ap.add_argument("--no-check", action="store_true",
@@ -116,17 +184,69 @@ def main():
                     help="rendezvous backend for N > 1; gloo lets ranks share a GPU to rehearse the multi-rank flow on a one-GPU box")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket kernels with HIP events in the timed region (no roofline block)")
-    args = ap.parse_args()
+    ap.add_argument("--sustained-seconds", type=float, default=2.5,
+                    help="length of the untimed-by-the-driver loop behind `roofline.sustained` (0 = skip)")
+    ap.add_argument("--no-one-lane", action="store_true", help="skip the one-lane per-kernel table")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch, rendezvous, barrier and the max-over-ranks only: no GPU work, value = null "
+                         "(exercises the N-rank start-up on a box without a GPU)")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv):
+    """`--gpus N` outside torch.distributed.run: start the N ranks as a child job (main-mpi.cc:642-665 brings up
+    its own ranks the same way through mpiexec).  Nothing in this process has touched the GPU or imported torch."""
+    with socket.socket() as s:                      # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus < 1:
+        print("bench: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        print(f"bench: --gpus {args.gpus} but torch.distributed.run started {world_env} ranks", file=sys.stderr)
+        return 2
 
     import torch                      # device memory, streams and torch.distributed: plumbing
-    import ntt_amd                    # the product: HIP kernels behind the C ABI
-    from ntt_amd import shard
+    from ntt_amd import shard   # host-side rank helpers (importing the package loads the C-ABI library; no GPU call)
 
     rank, world, local_rank = shard.env_rank_world()
+    if args.dry_run:
+        group = shard.Group("gloo")
+        if group.world != args.gpus:
+            return 2
+        group.barrier()
+        t0 = time.perf_counter()
+        group.barrier()
+        elapsed = group.max_over_ranks(time.perf_counter() - t0)
+        if rank == 0:
+            print(json.dumps({"metric": "poly-mults/sec at n=2^17 (32-bit p)", "value": None, "unit": "poly-mults/s",
+                              "n_gpus": group.world, "steps": 0, "warmup": 0, "ms_per_step": 1e3 * elapsed,
+                              "dry_run": True}), flush=True)
+        group.close()
+        return 0
+
+    import ntt_amd                    # the product: HIP kernels behind the C ABI
+
     if args.backend == "gloo":                        # rehearsal: ranks may share a GPU, exchanges on host tensors
         local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     group = shard.Group(args.backend, device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)   # RCCL when world > 1
+    if group.world != args.gpus:
+        print(f"bench: rank {rank}: world {group.world} != --gpus {args.gpus}", file=sys.stderr)
+        return 2
 
     B, n, p = args.batch, args.n, args.p
     stride = 2 * n
@@ -157,15 +277,15 @@ def main():
         step()
     sync()
 
-    # every rank checks the last product of its warm-up output before timing anything (no oracle here:
-    # the oracle comparison of pair 0 happens inside the cpu_baseline leg below)
+    # every rank checks products of its warm-up output before timing anything (no oracle here: the oracle
+    # comparison of pair 0 happens inside the cpu_baseline leg below): the first, the last and one in between
     gpu_row0 = None
     if not args.no_check:
-        row = B - 1
-        got = dab[row, :2 * n - 1].cpu().numpy().view(np.uint32)
-        if not evaluation_identity(ha[row], hb[row], got, p):
-            print(f"bench: rank {rank}: A(x) * B(x) != AB(x) on the GPU result", file=sys.stderr)
-            sys.exit(1)
+        for row in sorted({0, B // 2, B - 1}):
+            got = dab[row, :2 * n - 1].cpu().numpy().view(np.uint32)
+            if not evaluation_identity(ha[row], hb[row], got, p):
+                print(f"bench: rank {rank}: A(x) * B(x) != AB(x) on the GPU result, row {row}", file=sys.stderr)
+                return 1
         gpu_row0 = dab[0, :2 * n - 1].cpu().numpy().view(np.uint32).copy()
 
     # which kernel dominates (all kernels bracketed with events over two untimed steps); the timed region
@@ -193,30 +313,91 @@ def main():
 
     elapsed = group.max_over_ranks(elapsed)
 
+    # the same loop over >= 2 s (the board's power controller settles in ~0.5 s; the timed region above may be shorter)
+    sustained = None
+    if args.sustained_seconds > 0 and not args.no_kernel_timing:
+        reps = max(args.steps, int(args.sustained_seconds / max(elapsed / args.steps, 1e-6)) + 1)
+        barrier()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        sync()
+        barrier()
+        dt = group.max_over_ranks(time.perf_counter() - t1)
+        sustained = {"value": world * B * reps / dt, "seconds": dt, "steps": reps, "ms_per_step": 1e3 * dt / reps}
+
+    # uncontended per-kernel times: a second context with ONE stream lane, every kernel bracketed (untimed)
+    one_lane = None
+    if rank == 0 and not args.no_kernel_timing and not args.no_one_lane:
+        prev = os.environ.get("NTT_AMD_STREAMS")
+        os.environ["NTT_AMD_STREAMS"] = "1"
+        ctx1 = ntt_amd.Context(local_rank)
+        plan1 = ctx1.plan(p, n, B, kind)
+        if prev is None:
+            del os.environ["NTT_AMD_STREAMS"]
+        else:
+            os.environ["NTT_AMD_STREAMS"] = prev
+        plan1.multiply(da, db, out=dab, batch=B, out_stride=stride)
+        ctx1.synchronize()
+        ctx1.enable_kernel_timing(True)
+        for _ in range(3):
+            plan1.multiply(da, db, out=dab, batch=B, out_stride=stride)
+        ctx1.synchronize()
+        one_lane = {k: {"us_per_product": 1e3 * v[0] / (3 * B), "avg_launch_us": 1e3 * v[0] / v[1]}
+                    for k, v in ctx1.kernel_times().items() if v[1] > 0}
+        ctx1.enable_kernel_timing(False)
+        plan1.close()
+        ctx1.close()
+
+    rc = 0
     if rank == 0:
         units = world * B * args.steps
         value = units / elapsed
         alg_bytes = 16 * n - 4                      # read a, read b, write ab
-        # dominant kernel = largest share of device time in the timed region
         if args.no_kernel_timing:
             print(json.dumps({"value": value, "ms_per_step": 1e3 * elapsed / args.steps, "chunk": args.chunk}), flush=True)
             plan.close()
             ctx.close()
             group.close()
-            return
+            return 0
+        # dominant kernel = largest share of device time in the timed region
         name, (tot_ms, launches) = max(((k, v) for k, v in ktimes.items() if v[1] > 0),
                                        key=lambda kv: kv[1][0])
         units_per_launch = B * args.steps / launches
         avg_ms = tot_ms / launches
         achieved = alg_bytes * units_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        stamp = kernel_source_stamp()
+        traffic, traffic_info = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            per_unit = json.load(open(tpath)).get(name, {}).get("bytes_per_unit")
-            if per_unit:                 # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE) per launch, GB like achieved
+            tj = json.load(open(tpath))
+            per_unit = tj.get(name, {}).get("bytes_per_unit")
+            if per_unit:                 # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE) per launch, bytes
                 traffic = per_unit * units_per_launch
+                traffic_info = {"bytes_per_unit": per_unit, "measured_on_build": tj.get("_build"),
+                                "this_build": stamp, "same_build": tj.get("_build") == stamp,
+                                "kernel_own_GBps": per_unit * units_per_launch / (avg_ms * 1e-3) / 1e9}
+        # integer-VALU roofline (the bound DESIGN.md section 5 argues for): issue cycles per product from the
+        # instruction mix of the three kernels (profiles/valu_model.json, tools/valu_model.py) against the
+        # chip's SIMD cycles per second
+        valu = None
+        vpath = os.path.join(ROOT, "profiles", "valu_model.json")
+        if os.path.exists(vpath) and n == 131072 and not args.barrett:
+            vj = json.load(open(vpath))
+            cyc = sum(k["issue_cycles_per_product"] for k in vj["kernels"].values())
+            lane_ops = sum(k["lane_ops_per_product"] for k in vj["kernels"].values())
+            floor_us = 1e6 * cyc / SIMD_CYCLES_PER_S
+            valu = {"bound": "valu-int", "lane_ops_per_product": lane_ops, "issue_cycles_per_product": cyc,
+                    "peak": lane_ops / (cyc / SIMD_CYCLES_PER_S) / 1e12, "achieved": lane_ops * value / world / 1e12,
+                    "unit": "T lane-op/s", "floor_us_per_product": floor_us,
+                    "frac": floor_us / (1e6 * world / value),
+                    "per_kernel_issue_cycles": {k: v["issue_cycles_per_product"] for k, v in vj["kernels"].items()},
+                    "measured_on_build": vj.get("_build"), "same_build": vj.get("_build") == stamp,
+                    "note": "peak = this instruction mix at 2 / 4 issue cycles per wave64 instruction on 256 CUs x 4 SIMDs at 2.4 GHz"}
         out = {
-            "metric": "poly-mults/sec at n=2^17 (32-bit p)",
+            "metric": f"poly-mults/sec at n=2^{n.bit_length() - 1} (32-bit p)" if n & (n - 1) == 0
+                      else f"poly-mults/sec at n={n} (32-bit p)",
             "value": value,
             "unit": "poly-mults/s",
             "n_gpus": world,
@@ -236,19 +417,21 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": name, "avg_launch_ms": avg_ms, "launches": launches,
                          "units_per_launch": units_per_launch, "algorithmic_bytes_per_unit": alg_bytes,
+                         "traffic_detail": traffic_info,
                          "pipeline_achieved": value / world * alg_bytes / 1e9,
                          "pipeline_frac": value / world * alg_bytes / 1e9 / HBM_PEAK_GBPS,
-                         "kernel_ms_per_step_untimed": {k: v[0] / 2 for k, v in warm_ktimes.items()}},
+                         "kernel_ms_per_step_untimed": {k: v[0] / 2 for k, v in warm_ktimes.items()},
+                         "kernels_one_lane": one_lane, "valu": valu, "sustained": sustained},
         }
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(16, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(n, p, threads, args.cpu_seconds, gpu_row0)
+            out["cpu_baseline"] = cpu_baseline(n, p, args.cpu_seconds, gpu_row0)
         print(json.dumps(out), flush=True)
 
     plan.close()
     ctx.close()
     group.close()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

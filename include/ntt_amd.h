@@ -63,6 +63,7 @@ void poly_multiply(int *a, int *b, int *ab, int n, int p);
  * one process per GPU); ndev must be 1.  No reference counterpart (the reference's CUDA files
  * use the implicit device, e.g. main-montgomery-GPU.cu:383). */
 int ntt_ctx_create(const int *device_ids, int ndev, ntt_ctx **out_ctx);
+/* Destroy every plan made from a context BEFORE the context: a plan handle points into its context. */
 int ntt_ctx_destroy(ntt_ctx *ctx);
 /* Use an existing hipStream_t (passed as void*) for all work of this context; NULL restores the
  * context's own stream.  ntt_ctx_stream returns the stream in use (as void*). */

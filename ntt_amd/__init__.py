@@ -16,6 +16,7 @@ Arrays may be numpy arrays (host memory; the library stages them) or objects exp
 import ctypes as C
 import importlib.util
 import os
+import weakref
 
 import numpy as np
 
@@ -147,9 +148,14 @@ class Context:
         _check(_lib.ntt_ctx_create(C.byref(dev), 1, C.byref(h)))
         self._h = h
         self.device = device
+        self._plans = weakref.WeakSet()      # live plans: a plan's destroy call dereferences its context
 
     def close(self):
+        """Destroys the context after closing every plan made from it that is still open (a plan handle
+        holds a pointer to its context: destroying it later would be a use-after-free in native code)."""
         if self._h:
+            for pl in list(self._plans):
+                pl.close()
             _lib.ntt_ctx_destroy(self._h)
             self._h = None
 
@@ -259,10 +265,12 @@ class Plan:
         self._h = h
         self.ctx, self.p, self.n, self.batch, self.kind = ctx, int(p), int(n), int(batch), kind
         self.length = _lib.ntt_plan_length(h)
+        ctx._plans.add(self)
 
     def close(self):
         if self._h:
-            _lib.ntt_plan_destroy(self._h)
+            if self.ctx._h:                  # the context closes its plans first; never destroy against a dead one
+                _lib.ntt_plan_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -315,6 +323,7 @@ class NegacyclicPlan(Plan):
         self._h = h
         self.ctx, self.p, self.n, self.batch, self.kind = ctx, int(p), int(n), int(batch), kind
         self.length = _lib.ntt_plan_length(h)
+        ctx._plans.add(self)
 
     def multiply(self, a, b, out=None, batch=None, out_stride=None):
         """a, b: [batch, n] uint32 -> [batch, out_stride] uint32 holding the n coefficients of a*b mod x^n+1."""
@@ -342,10 +351,12 @@ class Plan64:
         L = C.c_uint32()
         _check(_lib.ntt_plan64_length(h, C.byref(L)))
         self.length = L.value
+        ctx._plans.add(self)
 
     def close(self):
         if self._h:
-            _lib.ntt_plan64_destroy(self._h)
+            if self.ctx._h:
+                _lib.ntt_plan64_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -378,10 +389,12 @@ class DistPlan:
         self._h = h
         self.ctx, self.p, self.lgL, self.world, self.rank = ctx, int(p), int(lgL), int(world), int(rank)
         self.local_length = _lib.ntt_dist_local_length(h)
+        ctx._plans.add(self)
 
     def close(self):
         if self._h:
-            _lib.ntt_dist_plan_destroy(self._h)
+            if self.ctx._h:
+                _lib.ntt_dist_plan_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -1,5 +1,4 @@
-// col16_body.hpp -- device body of the LDS-staged column pass (see kernels_col16.hip), shared by the
-// stand-alone kernel and the fused pipeline kernel (kernels_pipe.hip).
+// col16_body.hpp -- device body of the LDS-staged column pass (see kernels_col16.hip).
 #pragma once
 #include <type_traits>
 

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "../../include/ntt_amd.h"
 #include "engine.hpp"
@@ -155,6 +156,7 @@ try {
     launch_crt_merge(rows, dout, out_len, cc, ctx->stream);
     ctx->end();
     HIP_TRY(hipGetLastError());
+    if (int lrc_ = ntt::take_launch_error()) return lrc_;
     if (!dev_o) {
         HIP_TRY(hipMemcpyAsync(ab, dout, out_len * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -234,6 +236,7 @@ try {
     ctx->end();
     if ((rc = multiply_device_any(w.plans[k], ra, rb, dres, out_len, 1))) return rc;
     HIP_TRY(hipGetLastError());
+    if (int lrc_ = ntt::take_launch_error()) return lrc_;
     if (!dev_o) {
         HIP_TRY(hipMemcpyAsync(res, dres, out_len * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -280,6 +283,7 @@ try {
     launch_crt_merge(rows, dout, count, cc, ctx->stream);
     ctx->end();
     HIP_TRY(hipGetLastError());
+    if (int lrc_ = ntt::take_launch_error()) return lrc_;
     if (!dev_o) {
         HIP_TRY(hipMemcpyAsync(out, dout, count * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -293,6 +297,36 @@ NTT_CATCH_STATUS
 // ---- the reference's entry point ---------------------------------------------------------------------
 static ntt_ctx *g_ctx = nullptr;
 static std::mutex g_mu;
+// The harness calls this entry point with every (n, p) of its cases, 50 epochs each (main-montgomery.cc:309-323):
+// a handful of plans.  The cache is bounded so that a caller that sweeps many sizes does not accumulate work
+// buffers: beyond kMaxCachedPlans the least recently used plan is destroyed.
+static constexpr size_t kMaxCachedPlans = 8;
+static std::vector<std::array<uint64_t, 3>> g_plan_lru;            // most recently used last
+
+// The harness passes the same static arrays on every call (main-montgomery.cc:297: `int a[300000], b[300000],
+// ab[300000]`).  Page-locking them the first time they are seen lets the three copies of a call run as plain
+// DMA instead of going through the runtime's pageable staging.  An array is registered when the same (pointer,
+// size) arrives for the second time -- one-shot callers with transient arrays are left alone -- and the
+// registration is kept (a bounded number of ranges) and never repeated.  NTT_AMD_PIN_CALLER=0 turns it off.  A range that cannot be registered (already
+// registered by the caller, not page-lockable) simply stays pageable.
+struct PinnedRange { const void *ptr; size_t bytes; int seen; bool ok; };
+static std::vector<PinnedRange> g_pinned;
+static constexpr size_t kMaxPinnedRanges = 12;
+static void pin_caller_array(const void *ptr, size_t bytes)
+{
+    static const bool enabled = [] { const char *e = std::getenv("NTT_AMD_PIN_CALLER"); return !(e && e[0] == '0'); }();
+    if (!enabled || bytes < (64u << 10)) return;                 // small arrays: the registration costs more than it saves
+    for (auto &r : g_pinned) {
+        if (r.ptr != ptr || r.bytes != bytes) continue;
+        if (r.seen++ == 1) {                                     // second sight of the same array: a repeat caller
+            const hipError_t e = hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault);
+            if (e != hipSuccess) (void)hipGetLastError();
+            r.ok = e == hipSuccess;
+        }
+        return;
+    }
+    if (g_pinned.size() < kMaxPinnedRanges) g_pinned.push_back({ptr, bytes, 1, false});
+}
 
 extern "C" void poly_multiply(int *a, int *b, int *ab, int n, int p)
 try {
@@ -305,8 +339,8 @@ try {
         die("arguments");
     }
     ntt_plan *pl = nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);      // held across the multiply: an evicted plan is never one in use
     {
-        std::lock_guard<std::mutex> lk(g_mu);
         if (!g_ctx) {
             int dev = 0;
             if (ntt_ctx_create(&dev, 1, &g_ctx) != NTT_OK) die("ntt_ctx_create");
@@ -314,10 +348,26 @@ try {
         const std::array<uint64_t, 3> key{(uint64_t)(uint32_t)p, (uint64_t)n, (uint64_t)NTT_MODMUL_MONTGOMERY};
         auto it = g_ctx->plan_cache.find(key);
         if (it == g_ctx->plan_cache.end()) {
+            if (g_ctx->plan_cache.size() >= kMaxCachedPlans && !g_plan_lru.empty()) {
+                auto old = g_ctx->plan_cache.find(g_plan_lru.front());
+                if (old != g_ctx->plan_cache.end()) {
+                    ntt_plan_destroy(old->second);
+                    g_ctx->plan_cache.erase(old);
+                }
+                g_plan_lru.erase(g_plan_lru.begin());
+            }
             if (ntt_plan_create(g_ctx, (uint32_t)p, n, 1, NTT_MODMUL_MONTGOMERY, &pl) != NTT_OK) die("ntt_plan_create");
             g_ctx->plan_cache[key] = pl;
         } else {
             pl = it->second;
+            for (size_t i = 0; i < g_plan_lru.size(); ++i)
+                if (g_plan_lru[i] == key) { g_plan_lru.erase(g_plan_lru.begin() + (long)i); break; }
+        }
+        g_plan_lru.push_back(key);
+        if (hipSetDevice(g_ctx->device) == hipSuccess) {
+            pin_caller_array(a, (size_t)n * sizeof(int));
+            pin_caller_array(b, (size_t)n * sizeof(int));
+            pin_caller_array(ab, ((size_t)2 * n - 1) * sizeof(int));
         }
     }
     // int and uint32_t share their representation for values in [0, p), p < 2^31

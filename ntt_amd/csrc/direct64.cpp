@@ -261,6 +261,7 @@ int multiply_device(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64
         launch_row64_product(r, pl->mp, (unsigned)batch, s);
         cx->end();
         HIP_TRY(hipGetLastError());
+        if (int lrc_ = ntt::take_launch_error()) return lrc_;
         return NTT_OK;
     }
     if (pl->nlevels == 0) {
@@ -276,6 +277,7 @@ int multiply_device(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64
         launch_lds64(r, pl->mp, (unsigned)batch, s);
         cx->end();
         HIP_TRY(hipGetLastError());
+        if (int lrc_ = ntt::take_launch_error()) return lrc_;
         return NTT_OK;
     }
     // equal chunks of at most 96 MiB per work buffer (48 products at L = 2^18): the intermediates of a launch
@@ -322,6 +324,7 @@ int multiply_device(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64
         }
     }
     HIP_TRY(hipGetLastError());
+    if (int lrc_ = ntt::take_launch_error()) return lrc_;
     return NTT_OK;
 }
 

@@ -18,7 +18,7 @@
 namespace ntt {
 
 const char *const kKernelNames[K_COUNT] = {"col_fwd", "row_mul", "col_inv", "row_fwd", "row_inv",
-                                           "small", "permute", "crt_reduce", "crt_merge", "pipe",
+                                           "small", "permute", "crt_reduce", "crt_merge",
                                            "col64", "lds64"};
 
 static thread_local std::string g_err;
@@ -48,6 +48,19 @@ int exception_status() noexcept
     }
 }
 const char *last_error_cstr() { return g_err.c_str(); }
+
+static thread_local std::string g_bad_launch;
+void note_unsupported_launch(const char *what, int value)
+{
+    if (g_bad_launch.empty()) g_bad_launch = std::string(what) + " " + std::to_string(value);
+}
+int take_launch_error()
+{
+    if (g_bad_launch.empty()) return NTT_OK;
+    std::string msg;
+    msg.swap(g_bad_launch);
+    return fail(NTT_ERR_INTERNAL, "kernel launch skipped: " + msg);
+}
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
@@ -305,44 +318,6 @@ static RowArgs<MM> fill_row(ntt_plan *pl, const uint32_t *a0, const uint32_t *b0
     return a;
 }
 
-// Software-pipelined multiply (kernels_pipe.hip): launch t runs F(chunk t), R(chunk t-1), I(chunk t-2).
-template <class MM>
-static int multiply_pipelined(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
-                              size_t ab_stride, int batch)
-{
-    const uint32_t n = (uint32_t)pl->n, L = pl->L, out_len = 2 * n - 1, per = L >> kRowLog;
-    ntt_ctx *cx = pl->ctx;
-    const int K = (batch + pl->chunk - 1) / pl->chunk;
-    auto cb_of = [&](int c) { return (uint32_t)std::min(pl->chunk, batch - c * pl->chunk); };
-    auto w0_of = [&](int c) { return static_cast<uint32_t *>(pl->work0.ptr) + (size_t)(c % 3) * pl->chunk * L; };
-    auto w1_of = [&](int c) { return static_cast<uint32_t *>(pl->work1.ptr) + (size_t)(c % 3) * pl->chunk * L; };
-    for (int t = 0; t < K + 2; ++t) {
-        PipeArgs<MM> pa{};
-        pa.groups_per_product = per;
-        if (t < K) {
-            const size_t c0 = (size_t)t * pl->chunk;
-            pa.f = fill_col<MM>(pl, 0, false, a + c0 * n, b + c0 * n, w0_of(t), w1_of(t), n, L, n, L,
-                                pl->tw_fwd[0], false, {}, false);
-            pa.groups_f = cb_of(t) * per;
-        }
-        if (t >= 1 && t - 1 < K) {
-            pa.r = fill_row<MM>(pl, w0_of(t - 1), w1_of(t - 1), w0_of(t - 1));
-            pa.groups_r = cb_of(t - 1) * per;
-        }
-        if (t >= 2) {
-            const size_t c0 = (size_t)(t - 2) * pl->chunk;
-            pa.i = fill_col<MM>(pl, 0, true, w0_of(t - 2), nullptr, ab + c0 * ab_stride, nullptr, L, ab_stride,
-                                L, out_len, pl->tw_inv[0], true, pl->scale_mul, true);
-            pa.groups_i = cb_of(t - 2) * per;
-        }
-        const unsigned groups = std::max(pa.groups_f, std::max(pa.groups_r, pa.groups_i));
-        cx->begin(K_PIPE);
-        launch_pipe(pl->kind, pl->lazy, pl->level_log[0], &pa, pl->mp, groups, cx->cur);
-        cx->end();
-    }
-    return NTT_OK;
-}
-
 template <class MM>
 static void row_pass(ntt_plan *pl, int which, const uint32_t *a0, const uint32_t *b0, uint32_t *out,
                      unsigned rows)
@@ -435,16 +410,41 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
         cx->end();
         return NTT_OK;
     }
-    if (pl->pipe && !neg) return multiply_pipelined<MM>(pl, a, b, ab, ab_stride, batch);
     const int m = pl->nlevels;
     ntt_ctx *cx = pl->ctx;
     const int nchunks = (batch + pl->chunk - 1) / pl->chunk;
     int lanes = std::min(std::min(pl->lanes, cx->nlanes), nchunks);
     if (cx->lane_limit > 0) lanes = std::min(lanes, cx->lane_limit);
+    // Whatever ends this function (a failed HIP call between fork and join included), the context gets
+    // its own stream back as the launch target and every side lane that may hold work is joined into it,
+    // so that the next call on the context never runs on a half-ordered stream.
+    struct LaneJoin {
+        ntt_ctx *cx;
+        int forked = 0;                                   // side lanes 1 .. forked-1 were made to wait on the fork event
+        int join()
+        {
+            cx->cur = cx->stream;
+            int rc = NTT_OK;
+            for (int l = 1; l < forked; ++l) {
+                hipError_t e = hipEventRecord(cx->lane_done[l], cx->lane[l]);
+                if (e == hipSuccess) e = hipStreamWaitEvent(cx->stream, cx->lane_done[l], 0);
+                if (e != hipSuccess) {
+                    (void)hipStreamSynchronize(cx->lane[l]);     // last resort: order by waiting on the host
+                    rc = fail(NTT_ERR_HIP, std::string("joining stream lanes: ") + hipGetErrorString(e));
+                }
+            }
+            forked = 0;
+            return rc;
+        }
+        ~LaneJoin() { if (forked || cx->cur != cx->stream) (void)join(); }
+    } lanes_guard{cx};
     if (lanes > 1) {                                      // fork: side lanes start after prior work
         // ordering between the lanes is what keeps the results right: a failure here is an error, not a warning
         HIP_TRY(hipEventRecord(cx->fork_ev, cx->stream));
-        for (int l = 1; l < lanes; ++l) HIP_TRY(hipStreamWaitEvent(cx->lane[l], cx->fork_ev, 0));
+        for (int l = 1; l < lanes; ++l) {
+            lanes_guard.forked = l + 1;
+            HIP_TRY(hipStreamWaitEvent(cx->lane[l], cx->fork_ev, 0));
+        }
     }
     int ci = 0;
     for (int c0 = 0; c0 < batch; c0 += pl->chunk, ++ci) {
@@ -469,21 +469,16 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
         col_pass<MM>(pl, 0, true, false, w0, nullptr, ab + (size_t)c0 * ab_stride, nullptr, L, ab_stride,
                      L, out_len, pl->tw_inv[0], m == 1, pl->scale_mul, true, cb, 1, neg ? pl->twist_inv : nullptr);
     }
-    cx->cur = cx->stream;
-    if (lanes > 1) {                                      // join
-        for (int l = 1; l < lanes; ++l) {
-            HIP_TRY(hipEventRecord(cx->lane_done[l], cx->lane[l]));
-            HIP_TRY(hipStreamWaitEvent(cx->stream, cx->lane_done[l], 0));
-        }
-    }
-    return NTT_OK;
+    return lanes_guard.join();
 }
 
 int multiply_device_any(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
                         size_t ab_stride, int batch)
 {
-    return pl->kind == NTT_MODMUL_MONTGOMERY ? multiply_device<Mont32>(pl, a, b, ab, ab_stride, batch)
-                                             : multiply_device<Barrett32>(pl, a, b, ab, ab_stride, batch);
+    const int rc = pl->kind == NTT_MODMUL_MONTGOMERY ? multiply_device<Mont32>(pl, a, b, ab, ab_stride, batch)
+                                                     : multiply_device<Barrett32>(pl, a, b, ab, ab_stride, batch);
+    const int lrc = take_launch_error();                  // a dispatcher without a kernel for this shape launched nothing
+    return rc ? rc : lrc;
 }
 
 // Tile description for the LDS-staged digit reversal: dst[R(i)] = src[i] where i has the bit fields
@@ -912,13 +907,7 @@ static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_ki
         }
         pl->chunk = (int)chunk;
         pl->lanes = (int)std::min<long>(ctx->nlanes, (batch + chunk - 1) / chunk);
-        // Off by default: measured on MI355X the fused launch only matches the three separate
-        // kernels (roles do not overlap: F+R+I together take the sum of their solo times, see
-        // DESIGN.md section 8), so the simpler path stays the default.  NTT_AMD_PIPE=1 enables it.
-        pl->pipe = false;
-        if (const char *e = std::getenv("NTT_AMD_PIPE"))
-            pl->pipe = e[0] == '1' && m == 1 && pl->level_log[0] >= 5 && !negacyclic;
-        const long slots = pl->pipe ? std::min<long>(3, (batch + chunk - 1) / chunk) : pl->lanes;
+        const long slots = pl->lanes;
         int rc = pl->work0.ensure(per * chunk * slots);
         if (rc == NTT_OK) rc = pl->work1.ensure(per * chunk * slots);
         if (rc) { ntt_plan *raw = pl.release(); ntt_plan_destroy(raw); return rc; }
@@ -1010,6 +999,7 @@ static int multiply_entry(ntt_plan *pl, const uint32_t *a, const uint32_t *b, ui
     int rc = multiply_device_any(pl, pa, pb, pab, ab_stride, batch);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
+    if (int lrc_ = ntt::take_launch_error()) return lrc_;
     if (!dab) {
         HIP_TRY(hipMemcpyAsync(ab, pab, out_elems * 4, hipMemcpyDeviceToHost, cx->stream));
         HIP_TRY(hipStreamSynchronize(cx->stream));
@@ -1040,6 +1030,7 @@ static int transform_entry(ntt_plan *pl, uint32_t *data, int batch, bool inverse
                                                : transform_device<Barrett32>(pl, d, batch, inverse);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
+    if (int lrc_ = ntt::take_launch_error()) return lrc_;
     if (!dev) {
         HIP_TRY(hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, cx->stream));
         HIP_TRY(hipStreamSynchronize(cx->stream));
@@ -1195,6 +1186,7 @@ try {
         col_pass<Barrett32>(pl, 0, inv, false, data, nullptr, data, nullptr, S, S, S, S,
                             inv ? pl->tw_inv[0] : pl->tw_fwd[0], inv, dp->scale, true, 1, 1);
     HIP_TRY(hipGetLastError());
+    if (int lrc_ = ntt::take_launch_error()) return lrc_;
     return NTT_OK;
 }
 NTT_CATCH_STATUS

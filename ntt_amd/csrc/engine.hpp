@@ -16,7 +16,7 @@ namespace ntt {
 
 enum KernelId {
     K_COL_FWD = 0, K_ROW_MUL, K_COL_INV, K_ROW_FWD, K_ROW_INV, K_SMALL, K_PERMUTE, K_CRT_REDUCE,
-    K_CRT_MERGE, K_PIPE, K_COL64, K_LDS64, K_COUNT
+    K_CRT_MERGE, K_COL64, K_LDS64, K_COUNT
 };
 extern const char *const kKernelNames[K_COUNT];
 
@@ -43,6 +43,8 @@ void crt_release(ntt_ctx *ctx);
 struct StreamState;                       // stream.cpp: ring of device slots + copy streams
 void stream_release(ntt_ctx *ctx);
 const char *last_error_cstr();
+// NTT_OK, or NTT_ERR_INTERNAL (and the message) if a dispatcher skipped a launch since the last call; clears the mark
+int take_launch_error();
 bool is_device_ptr(const void *p);
 
 // device-pointer entry used by the CRT path (caller holds ctx->mu)
@@ -123,9 +125,6 @@ struct ntt_plan {
     // LDS-staged column kernel per direction (NTT_AMD_COL16 bit 0 = forward, bit 1 = inverse).
     // Measured at L = 2^18: inverse 22 % faster with it, forward 7 % slower (profiles/).
     bool col16_fwd = false, col16_inv = true;
-    // Software-pipelined fused launch (kernels_pipe.hip) for single-level plans with N1 >= 32;
-    // NTT_AMD_PIPE=1 enables it (default: three separate kernels).
-    bool pipe = false;
     ntt::DeviceBuffer work0, work1;
     std::vector<void *> owned;          // device allocations to free
 };

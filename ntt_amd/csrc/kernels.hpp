@@ -68,16 +68,6 @@ struct FusedArgs {
     const typename MM::tw_t *tw_fwd, *tw_inv;
 };
 
-// One launch of the software-pipelined fused kernel (kernels_pipe.hip): forward columns of
-// chunk t, row multiply of chunk t-1, inverse columns of chunk t-2.  groups_* = number of column
-// tiles / rows each role owns in this launch (0 = role idle while the pipeline fills or drains).
-template <class MM>
-struct PipeArgs {
-    ColArgs<MM> f, i;
-    RowArgs<MM> r;
-    uint32_t groups_f, groups_r, groups_i, groups_per_product;
-};
-
 template <class MM>
 struct SmallArgs {
     const uint32_t *a, *b;
@@ -104,6 +94,11 @@ struct CrtConsts {
     uint64_t mR[4];                      // m_k * 2^64 mod p64
 };
 
+// A launch_* dispatcher that has no kernel for the shape it is asked for launches nothing and records it
+// here (sticky, per thread); the entry points turn it into NTT_ERR_INTERNAL beside hipGetLastError
+// (engine.cpp: take_launch_error), so a skipped launch can never return NTT_OK over stale work buffers.
+void note_unsupported_launch(const char *what, int value);
+
 // kind: 0 Montgomery, 1 Barrett; lazy: values kept in [0,2p) (needs 4p <= 2^32)
 void launch_col(int kind, bool lazy, int logN1, bool inverse, bool half_in, const void *args,
                 const ModParams &mp, unsigned cols_per_row, unsigned batch, unsigned nops,
@@ -111,8 +106,6 @@ void launch_col(int kind, bool lazy, int logN1, bool inverse, bool half_in, cons
 void launch_col16(int kind, bool lazy, int logN1, bool inverse, bool half_in, const void *args,
                   const ModParams &mp, unsigned cols_per_row, unsigned batch, unsigned nops,
                   hipStream_t s);
-void launch_pipe(int kind, bool lazy, int logN1, const void *args, const ModParams &mp, unsigned groups,
-                 hipStream_t s);
 void launch_row_mul(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);
 // the same launch with the kernel's own start / stop events (hipExtLaunchKernelGGL): kernel timing without the
 // extra queue packets of hipEventRecord around it

@@ -106,7 +106,7 @@ static void launch_col_l(int logN1, bool inverse, bool half_in, const ColArgs<MM
     case 4: launch_col_t<MM, LAZY, 4>(inverse, half_in, a, mp, grid, s); break;
     case 5: launch_col_t<MM, LAZY, 5>(inverse, half_in, a, mp, grid, s); break;
     case 6: launch_col_t<MM, LAZY, 6>(inverse, half_in, a, mp, grid, s); break;
-    default: break;
+    default: note_unsupported_launch("col_kernel: no instantiation for log2(N1) =", logN1); break;
     }
 }
 

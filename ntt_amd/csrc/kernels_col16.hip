@@ -43,7 +43,8 @@ static void launch_l(int logN1, bool inverse, bool half_in, const ColArgs<MM> &a
     if (logN1 == 8) launch_t<MM, LAZY, 4>(inverse, half_in, a, mp, dim3(cols_per_row / 64, batch, nops), s);
     else if (logN1 == 7) launch_t<MM, LAZY, 3>(inverse, half_in, a, mp, dim3(cols_per_row / 64, batch, nops), s);
     else if (logN1 == 6) launch_t<MM, LAZY, 2>(inverse, half_in, a, mp, dim3(cols_per_row / 64, batch, nops), s);
-    else launch_t<MM, LAZY, 1>(inverse, half_in, a, mp, dim3(cols_per_row / 128, batch, nops), s);
+    else if (logN1 == 5) launch_t<MM, LAZY, 1>(inverse, half_in, a, mp, dim3(cols_per_row / 128, batch, nops), s);
+    else note_unsupported_launch("col16_kernel: no instantiation for log2(N1) =", logN1);
 }
 
 void launch_col16(int kind, bool lazy, int logN1, bool inverse, bool half_in, const void *args,

@@ -186,7 +186,7 @@ void launch_permute_tiled(const PermTileArgs &pa, unsigned batch, hipStream_t s)
     case 11: hipLaunchKernelGGL(permute_tiled_kernel<11>, grid, dim3(256), lds, s, pa); break;
     case 12: hipLaunchKernelGGL(permute_tiled_kernel<12>, grid, dim3(256), lds, s, pa); break;
     case 13: hipLaunchKernelGGL(permute_tiled_kernel<13>, grid, dim3(256), lds, s, pa); break;
-    default: break;                                                        // make_perm_tile only builds these
+    default: note_unsupported_launch("permute_tiled_kernel: no instantiation for tile bits =", pa.a + pa.b); break;   // make_perm_tile only builds these
     }
 }
 

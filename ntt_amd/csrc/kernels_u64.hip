@@ -255,7 +255,7 @@ static void launch_col64_a(int logN1, bool inverse, bool half_in, const Col64Arg
     case 2: launch_col64_t<A, 2>(inverse, half_in, a, mp, grid, s); break;
     case 3: launch_col64_t<A, 3>(inverse, half_in, a, mp, grid, s); break;
     case 4: launch_col64_t<A, 4>(inverse, half_in, a, mp, grid, s); break;
-    default: break;
+    default: note_unsupported_launch("col64_kernel: no instantiation for log2(N1) =", logN1); break;
     }
 }
 
@@ -379,6 +379,8 @@ void launch_col64x(int logN1, bool inverse, bool half_in, const Col64Args &a, co
         NTT_U64_DISPATCH(mp, (launch_col64x_t<M64, 2>(inverse, half_in, a, mp, grid, s)),
                          (launch_col64x_t<F64, 2>(inverse, half_in, a, mp, grid, s)),
                          (launch_col64x_t<F64L, 2>(inverse, half_in, a, mp, grid, s)));
+    } else if (logN1 != 5) {
+        note_unsupported_launch("col64x_kernel: no instantiation for log2(N1) =", logN1);
     } else {
         NTT_U64_DISPATCH(mp, (launch_col64x_t<M64, 1>(inverse, half_in, a, mp, grid, s)),
                          (launch_col64x_t<F64, 1>(inverse, half_in, a, mp, grid, s)),

@@ -1,5 +1,5 @@
 // row_body.hpp -- device bodies of the 4096-point row transforms (see kernels_row.hip), shared by
-// the stand-alone kernels and the fused pipeline kernel (kernels_pipe.hip).
+// the stand-alone kernels and the one-kernel products (kernels_fused.hip).
 #pragma once
 #include "device_ntt.hpp"
 

@@ -77,6 +77,11 @@ def main(argv=None):
     device = torch.device("cuda", dev_index) if on_gpu else torch.device("cpu")
     group = shard.Group(args.backend, device=device if on_gpu else None)
     ctx = ntt_amd.Context(dev_index)
+    if on_gpu:
+        # one stream for torch's collectives / fills and the library's kernels: the all-to-all's output is
+        # ordered before the merge that reads it and the residue kernels before the exchange that sends them,
+        # without a host synchronisation in between
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     if rank == 0:
         print(f"{world} ranks, one GPU each ({args.backend})" if on_gpu else
               f"{world} ranks on {min(world, ndev)} GPU(s) ({args.backend})", flush=True)
@@ -110,17 +115,15 @@ def main(argv=None):
         if not single:
             a_op, b_op = (a, b) if on_gpu else (a.numpy().view(np.uint64), b.numpy().view(np.uint64))
 
-            def residue_fn(k):
-                r = torch.zeros(2 * n - 1, dtype=torch.int32, device=device)
+            def residue_fn(k):                                   # the library overwrites all 2n-1 entries
+                r = torch.empty(2 * n - 1, dtype=torch.int32, device=device)
                 ctx.crt_residue_multiply(a_op, b_op, k, out=r if on_gpu else r.numpy().view(np.uint32))
-                ctx.synchronize()
-                return r
+                return r                                         # on_gpu: queued on torch's stream (see above)
 
             def merge_fn(rows, count):
-                m = torch.zeros(count, dtype=torch.int64, device=device)
+                m = torch.empty(count, dtype=torch.int64, device=device)
                 ctx.crt_merge(rows if on_gpu else [r.numpy().view(np.uint32) for r in rows], p,
                               out=m if on_gpu else m.numpy().view(np.uint64), count=count)
-                ctx.synchronize()
                 return m
 
             if world == 1:                                       # all four primes and the merge on this rank

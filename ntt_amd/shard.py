@@ -85,9 +85,11 @@ def crt_multiply_sharded(group, residue_fn, merge_fn, n, device="cpu"):
     residue_fn(k) -> int32 torch tensor [2n-1] (u32 bit pattern) with the product mod prime k;
     merge_fn(rows, count) -> int64 torch tensor [count] from four int32 tensors [count].
     Returns an int64 torch tensor [2n-1] (u64 bit pattern), identical on every rank.
-    The callbacks must hand back tensors whose producing work is complete with respect to torch's
-    current stream (the library runs on its own stream: synchronise the context, or give it torch's
-    stream with Context.set_stream).
+    The tensors handed to merge_fn come out of all_to_all_single / .contiguous() on torch's CURRENT
+    stream, and what residue_fn returns is sent from that stream: with device tensors the library must
+    run on the same stream (Context.set_stream(torch.cuda.current_stream().cuda_stream), as
+    ntt_amd.launch does) or the callbacks must synchronise both ways themselves -- the context's own
+    stream is not ordered against torch's.
     """
     import torch
     world, rank = group.world, group.rank

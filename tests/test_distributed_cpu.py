@@ -75,3 +75,22 @@ def test_dist_transform_gloo(tmp_path, world):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     assert out.read_text() == "ok"
+
+
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with no torchrun around it (the way the driver calls it): bench.py starts
+    the two ranks itself as a child job (main-mpi.cc:642-665 brings up its ranks the same way) and rank 0 prints
+    ONE line with n_gpus == 2.  No GPU here, so --dry-run stops after the rendezvous, barrier and max-over-ranks."""
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--dry-run"], env=env, capture_output=True, text=True,
+                       timeout=280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert json.loads(lines[0])["n_gpus"] == 2
+    # a world that differs from --gpus is an error, not a silent one-rank run
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"],
+                       env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "started 3 ranks" in r.stderr

@@ -86,3 +86,21 @@ def test_launcher_rank_layout(tmp_path, nttdata, world, backend):
     r = subprocess.run(cmd[:-8] + ["--begin", "3", "--end", "3", "--epochs", "1", "--backend", backend],
                        env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 1 and "多项式乘法结果错误" in r.stdout
+
+
+def test_bench_gpus_flag_on_one_gpu():
+    """bench.py called the way the driver calls it for N > 1 (no torchrun wrapper): it starts its two ranks itself;
+    over gloo both share this box's GPU.  One JSON line from rank 0 with n_gpus == 2; every rank has checked rows of
+    its own output before timing."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--batch", "96", "--sustained-seconds", "0"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["config"]["batch_per_gpu"] == 96 and j["roofline"]["kernel"] in ("row_mul", "col_fwd", "col_inv")

@@ -274,26 +274,6 @@ def test_chunking_is_transparent(nt, ctx):
     assert np.array_equal(outs[0][6], orc.poly_multiply(a[6], b[6], p))
 
 
-def test_pipelined_fused_kernel(ctx):
-    # NTT_AMD_PIPE=1: one launch runs forward columns of chunk t, rows of chunk t-1 and inverse
-    # columns of chunk t-2 (kernels_pipe.hip); results must equal the three-kernel path
-    rng = np.random.default_rng(23)
-    os.environ["NTT_AMD_PIPE"] = "1"
-    try:
-        for n, batch, p, chunk, kind in ((131072, 7, 998244353, "2", 0), (65536, 5, 469762049, "1", 1),
-                                         (100000, 3, 1224736769, "3", 0), (131072, 2, 7340033, "8", 0)):
-            os.environ["NTT_AMD_CHUNK"] = chunk
-            a, b = rand_poly(rng, n, p, batch), rand_poly(rng, n, p, batch)
-            plan = ctx.plan(p, n, batch, kind)
-            got = plan.multiply(a, b)
-            for r in range(batch):
-                assert np.array_equal(got[r], orc.poly_multiply(a[r], b[r], p, kind="barrett")), (n, r)
-            plan.close()
-    finally:
-        del os.environ["NTT_AMD_PIPE"]
-        os.environ.pop("NTT_AMD_CHUNK", None)
-
-
 # ---- size-independent properties at the benchmark size ---------------------------------------------
 def test_full_size_properties(ctx):
     """n = 2^17, p = 998244353, batch 64 (BASELINE configs[1] shape): checks that need no oracle run
