@@ -91,6 +91,23 @@ int ntt_plan_length(const ntt_plan *plan);
 int ntt_poly_multiply_batched(ntt_plan *plan, const uint32_t *a, const uint32_t *b, uint32_t *ab,
                               size_t ab_stride, int batch);
 
+/* The same products for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc): NO counterpart in the reference.  Same arguments and results as
+ * ntt_poly_multiply_batched (bit for bit), with these differences:
+ *   - a, b, ab must be DEVICE pointers (a host array would need a staging allocation: NTT_ERR_INVALID);
+ *   - the intermediates of the transform passes live in a static device array of 64 MiB inside the library
+ *     (one copy per GPU, held until the process ends) instead of the plan's work buffers; a product needs
+ *     2 * L * 4 bytes of it (L = ntt_plan_length), so plans up to L = 2^23 (n <= 2^22) are served and longer
+ *     ones are rejected with NTT_ERR_UNSUPPORTED; batch <= 65535 (any batch the plan was or was not sized for:
+ *     the products go through the scratch array in groups of floor(64 MiB / (8 L)));
+ *   - one stream (the context's), no kernel-timing events; the call makes no hipMalloc / hipFree / event or
+ *     stream creation.  Asynchronous: results are complete after ntt_ctx_synchronize;
+ *   - every call on a GPU shares that GPU's scratch array: calls that overlap in time on one GPU (two contexts,
+ *     or one context whose stream the caller changed between calls without ordering them) race.
+ * Not for negacyclic plans. */
+int ntt_poly_multiply_batched_noalloc(ntt_plan *plan, const uint32_t *a, const uint32_t *b, uint32_t *ab,
+                                      size_t ab_stride, int batch);
+
 /* Negacyclic products: c = a * b mod (x^n + 1, p), n a power of two with
  * 2n | p - 1: a, b are [batch][n] u32, c is [batch][n] canonical residues with row stride c_stride
  * (>= n).  One transform of length n per operand (no zero padding); the twist by psi^i

@@ -37,7 +37,7 @@ MONTGOMERY, BARRETT = 0, 1
 EXPORTED_SYMBOLS = (
     "poly_multiply", "ntt_ctx_create", "ntt_ctx_destroy", "ntt_ctx_set_stream", "ntt_ctx_stream",
     "ntt_ctx_synchronize", "ntt_plan_create", "ntt_plan_destroy", "ntt_plan_length",
-    "ntt_poly_multiply_batched", "ntt_forward", "ntt_inverse", "ntt_crt_multiply", "ntt_crt_multiply_batched", "ntt_crt_prime",
+    "ntt_poly_multiply_batched", "ntt_poly_multiply_batched_noalloc", "ntt_forward", "ntt_inverse", "ntt_crt_multiply", "ntt_crt_multiply_batched", "ntt_crt_prime",
     "ntt_negacyclic_plan_create", "ntt_negacyclic_multiply_batched",
     "ntt_negacyclic_plan64_create", "ntt_negacyclic_multiply64_batched",
     "ntt_plan64_create", "ntt_plan64_destroy", "ntt_plan64_length", "ntt_poly_multiply64_batched",
@@ -74,6 +74,7 @@ def _load():
     lib.ntt_plan_destroy.argtypes = [vp]
     lib.ntt_plan_length.argtypes = [vp]
     lib.ntt_poly_multiply_batched.argtypes = [vp, vp, vp, vp, sz, i32]
+    lib.ntt_poly_multiply_batched_noalloc.argtypes = [vp, vp, vp, vp, sz, i32]
     lib.ntt_forward.argtypes = [vp, vp, i32]
     lib.ntt_inverse.argtypes = [vp, vp, i32]
     lib.ntt_crt_multiply.argtypes = [vp, vp, vp, vp, i32, u64]
@@ -290,6 +291,16 @@ class Plan:
         need_out = (batch - 1) * out_stride + 2 * self.n - 1
         _check(_lib.ntt_poly_multiply_batched(self._h, _ptr(a, np.uint32, batch * self.n), _ptr(b, np.uint32, batch * self.n),
                                               _ptr(out, np.uint32, need_out), out_stride, batch))
+        return out
+
+    def multiply_noalloc(self, a, b, out, batch, out_stride=None):
+        """``ntt_poly_multiply_batched_noalloc``: device tensors only, intermediates in the library's static
+        scratch array, nothing allocated by the call; `batch` need not fit the plan's capacity."""
+        if out_stride is None:
+            out_stride = 2 * self.n - 1
+        need_out = (batch - 1) * out_stride + 2 * self.n - 1
+        _check(_lib.ntt_poly_multiply_batched_noalloc(self._h, _ptr(a, np.uint32, batch * self.n), _ptr(b, np.uint32, batch * self.n),
+                                                      _ptr(out, np.uint32, need_out), out_stride, batch))
         return out
 
     def multiply_stream(self, a, b, out=None, out_stride=None):

@@ -15,6 +15,16 @@
 
 #include "../../include/ntt_amd.h"
 
+// ---- scratch of ntt_poly_multiply_batched_noalloc -----------------------------------------------------
+// The one entry point that allocates nothing keeps the intermediates of the 4-step passes (the role of
+// ntt_plan::work0 / work1) in this file-scope device array instead of hipMalloc'ed buffers.  Every GPU the
+// library runs on holds its own copy, at its own address, until the process ends.  In host code the
+// array's NAME is only a stand-in for the symbol: its device address is asked for once per device
+// (hipGetSymbolAddress in ntt_ctx_create, that device current) and kept in ntt_ctx::scratch; kernels,
+// like every other use of the memory, get that pointer, never the name.
+static constexpr size_t kScratchBytes = (size_t)64 << 20;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
 namespace ntt {
 
 const char *const kKernelNames[K_COUNT] = {"col_fwd", "row_mul", "col_inv", "row_fwd", "row_inv",
@@ -361,15 +371,22 @@ static void small_pass(ntt_plan *pl, int mode, const uint32_t *a0, const uint32_
     cx->end();
 }
 
-// a, b, ab: DEVICE pointers.
+// Where a multiply keeps the intermediates of its passes when they are not the plan's own work buffers:
+// room for `chunk` products (w0 / w1: chunk * L words each), one stream lane.
+struct WorkArea {
+    uint32_t *w0, *w1;
+    int chunk;
+};
+
+// a, b, ab: DEVICE pointers.  area == nullptr: the plan's work buffers and lanes.
 template <class MM>
 static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
-                           size_t ab_stride, int batch)
+                           size_t ab_stride, int batch, const WorkArea *area = nullptr)
 {
     // negacyclic plans: L = n, no zero padding, n outputs, operands and result twisted by psi^(+-i)
     const bool neg = pl->negacyclic;
     const uint32_t n = (uint32_t)pl->n, L = pl->L, out_len = neg ? n : 2 * n - 1;
-    if (pl->wide) return multiply_device<MM>(pl->wide, a, b, ab, ab_stride, batch);
+    if (pl->wide) return multiply_device<MM>(pl->wide, a, b, ab, ab_stride, batch, area);
     pl->ctx->cur = pl->ctx->stream;
     if (pl->logL == kRowLog && pl->twA) {
         Row4096Args<MM> ra{};
@@ -412,8 +429,11 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
     }
     const int m = pl->nlevels;
     ntt_ctx *cx = pl->ctx;
-    const int nchunks = (batch + pl->chunk - 1) / pl->chunk;
-    int lanes = std::min(std::min(pl->lanes, cx->nlanes), nchunks);
+    const int chunk = area ? area->chunk : pl->chunk;
+    uint32_t *const base0 = area ? area->w0 : static_cast<uint32_t *>(pl->work0.ptr);
+    uint32_t *const base1 = area ? area->w1 : static_cast<uint32_t *>(pl->work1.ptr);
+    const int nchunks = (batch + chunk - 1) / chunk;
+    int lanes = area ? 1 : std::min(std::min(pl->lanes, cx->nlanes), nchunks);
     if (cx->lane_limit > 0) lanes = std::min(lanes, cx->lane_limit);
     // Whatever ends this function (a failed HIP call between fork and join included), the context gets
     // its own stream back as the launch target and every side lane that may hold work is joined into it,
@@ -447,12 +467,12 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
         }
     }
     int ci = 0;
-    for (int c0 = 0; c0 < batch; c0 += pl->chunk, ++ci) {
+    for (int c0 = 0; c0 < batch; c0 += chunk, ++ci) {
         const int l = ci % lanes;
         cx->cur = l == 0 ? cx->stream : cx->lane[l];
-        uint32_t *w0 = static_cast<uint32_t *>(pl->work0.ptr) + (size_t)l * pl->chunk * L;
-        uint32_t *w1 = static_cast<uint32_t *>(pl->work1.ptr) + (size_t)l * pl->chunk * L;
-        const unsigned cb = (unsigned)std::min(pl->chunk, batch - c0);
+        uint32_t *w0 = base0 + (size_t)l * chunk * L;
+        uint32_t *w1 = base1 + (size_t)l * chunk * L;
+        const unsigned cb = (unsigned)std::min(chunk, batch - c0);
         const uint32_t *ca = a + (size_t)c0 * n, *cbp = b + (size_t)c0 * n;
         // forward column levels (both operands per launch); level 0 reads the caller's arrays with
         // implicit zero padding (n <= L/2: the upper half of every column is zero)
@@ -688,6 +708,16 @@ try {
         return fail(NTT_ERR_UNSUPPORTED, std::string("ntt_ctx_create: kernels are built for gfx950, device is ") + prop.gcnArchName);
     auto *cx = new ntt_ctx();
     cx->device = dev;
+    {   // this device's copy of the scratch array (device `dev` is current): its address, never the array's name
+        void *sp = nullptr;
+        const hipError_t se = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
+        if (se != hipSuccess || !sp) {
+            delete cx;
+            return fail(NTT_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(se));
+        }
+        cx->scratch = sp;
+        cx->scratch_bytes = kScratchBytes;
+    }
     hipError_t e = hipStreamCreateWithFlags(&cx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete cx;
@@ -1008,6 +1038,45 @@ static int multiply_entry(ntt_plan *pl, const uint32_t *a, const uint32_t *b, ui
     }
     return NTT_OK;
 }
+
+// The variant of ntt_poly_multiply_batched that allocates nothing (include/ntt_amd.h): device pointers only,
+// intermediates in this device's copy of the static scratch array, one stream lane, no kernel-timing events.
+int ntt_poly_multiply_batched_noalloc(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
+                                      size_t ab_stride, int batch)
+try {
+    if (!pl || !a || !b || !ab) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched_noalloc: null argument");
+    if (pl->negacyclic) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched_noalloc: not for negacyclic plans");
+    if (batch <= 0) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched_noalloc: batch must be positive");
+    if (batch > 65535) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched_noalloc: batch above 65535");
+    const size_t n = (size_t)pl->n, out_len = 2 * n - 1;
+    if (ab_stride < out_len) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched_noalloc: output row stride below the row length");
+    ntt_ctx *cx = pl->ctx;
+    std::lock_guard<std::mutex> lk(cx->mu);
+    HIP_TRY(hipSetDevice(cx->device));
+    if (!is_device_ptr(a) || !is_device_ptr(b) || !is_device_ptr(ab))
+        return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched_noalloc: a, b and ab must be device pointers (staging a host array would allocate)");
+    WorkArea area{nullptr, nullptr, batch};
+    const ntt_plan *shape = pl->wide ? pl->wide : pl;
+    if (shape->logL > kRowLog && !shape->fused) {          // the shapes whose passes hand intermediates over in memory
+        const size_t per = 2 * (size_t)shape->L * sizeof(uint32_t);          // both operands of one product
+        if (!cx->scratch || per > cx->scratch_bytes)
+            return fail(NTT_ERR_UNSUPPORTED, "ntt_poly_multiply_batched_noalloc: transform length " + std::to_string(shape->L) +
+                                                 " needs " + std::to_string(per) + " bytes of scratch per product, the static scratch array holds " +
+                                                 std::to_string(cx->scratch_bytes) + " (n up to 2^22)");
+        area.chunk = (int)std::min<size_t>((size_t)batch, cx->scratch_bytes / per);
+        area.w0 = static_cast<uint32_t *>(cx->scratch);
+        area.w1 = area.w0 + (size_t)area.chunk * shape->L;
+    }
+    const bool timing = cx->timing;                        // stamping a launch may create events: not on this path
+    cx->timing = false;
+    const int rc = pl->kind == NTT_MODMUL_MONTGOMERY ? multiply_device<Mont32>(pl, a, b, ab, ab_stride, batch, &area)
+                                                     : multiply_device<Barrett32>(pl, a, b, ab, ab_stride, batch, &area);
+    cx->timing = timing;
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return take_launch_error();
+}
+NTT_CATCH_STATUS
 
 static int transform_entry(ntt_plan *pl, uint32_t *data, int batch, bool inverse)
 {

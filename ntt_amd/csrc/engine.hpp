@@ -67,6 +67,10 @@ struct ntt_ctx {
     hipEvent_t fork_ev = nullptr;
     hipStream_t cur = nullptr;                        // stream the next kernel goes to
     int lane_limit = 0;                               // > 0: use at most this many lanes (stream.cpp)
+    // this device's copy of the static scratch array of ntt_poly_multiply_batched_noalloc (engine.cpp): its
+    // address from hipGetSymbolAddress at context creation, the pointer every use of that memory goes through
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
     std::mutex mu;                                    // serialises calls on this handle
 
     // per-kernel timing (bench.py roofline block)
