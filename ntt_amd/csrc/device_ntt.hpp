@@ -29,8 +29,15 @@ struct Ops {
     // csub(sub_raw()) form costs 4)
     static __device__ __forceinline__ uint32_t sub(uint32_t u, uint32_t v, const ModParams &m)
     {
+#if !defined(NTT_CSUB_MIN)                        // borrow-out + select, as csub() in modarith.hpp
+        uint32_t d0, r;
+        asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_add_u32 %1, %4, %0\n\tv_cndmask_b32 %1, %0, %1, vcc"
+            : "=&v"(d0), "=&v"(r) : "v"(u), "v"(v), "s"(bound(m)) : "vcc");
+        return r;
+#else
         const uint32_t d = u - v, e = d + bound(m);
         return e < d ? e : d;
+#endif
     }
     static __device__ __forceinline__ uint32_t mul_tw(uint32_t x, tw_t w, const ModParams &m)
     {

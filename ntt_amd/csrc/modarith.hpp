@@ -131,12 +131,22 @@ NTT_HD uint32_t mulhi32(uint32_t a, uint32_t b)
 #endif
 }
 
-// x in [0, 2m) -> [0, m).  (A v_sub_co_u32 + v_cndmask_b32 form was A/B-tested on MI355X and is
-// 3 % slower end to end than this v_sub_u32 + v_min_u32 form.)
+// x in [0, 2m) -> [0, m).  On the device: subtract with borrow-out + select, two full-rate instructions
+// (2 + 2 issue cycles per wave64) instead of v_sub_u32 + the half-rate v_min_u32 (2 + 4).  Written as one asm
+// block: left to the compiler the C++ form of it becomes v_cmp (half rate) + v_cndmask or picks up s_nop
+// hazard padding, which is how round 1 measured this idea 3 % slower; as a pinned pair it is 2 % faster end to
+// end (profiles/ab_csub_r02.txt) and 9 % fewer VALU issue cycles in the row kernel.  -DNTT_CSUB_MIN restores
+// the subtract + minimum form.
 NTT_HD uint32_t csub(uint32_t x, uint32_t m)
 {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTT_CSUB_MIN)
+    uint32_t t, r;
+    asm("v_subrev_co_u32 %0, vcc, %2, %3\n\tv_cndmask_b32 %1, %0, %3, vcc" : "=&v"(t), "=v"(r) : "s"(m), "v"(x) : "vcc");
+    return r;
+#else
     uint32_t t = x - m;
     return t < x ? t : x;       // unsigned min(x, x - m): x - m wraps high when x < m
+#endif
 }
 
 // ---- Montgomery, R = 2^32 ------------------------------------------------------------------

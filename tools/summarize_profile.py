@@ -82,6 +82,20 @@ def main():
             out.write(f"| {k} | {s['launches']} | {s['avg_us']:.1f} | {s['total_ms']:.2f} | {rd} | {wr} | "
                       f"{valu:.0f} | {lds} | {hit:.2f} |\n")
     print(open(os.path.join(dst, f"{tag}_summary.md")).read())
+    # profiles/traffic.json feeds bench.py's roofline.traffic: PMC bytes per product and kernel of THIS build
+    # (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md "HBM"), stamped with the sha256 of the kernel sources
+    sys.path.insert(0, ROOT)
+    import bench
+    units = 1024 / 22.0                                  # bench.py's default batch in 22 launch groups
+    names = {"col_kernel_fwd": "col_fwd", "col16_kernel_fwd": "col_fwd", "row_mul_kernel": "row_mul",
+             "col16_kernel_inv": "col_inv", "col_kernel_inv": "col_inv"}
+    traffic = {"_build": bench.kernel_source_stamp(), "_profile": tag}
+    for k, s in summary.items():
+        if k in names and "hbm_read_bytes_x2" in s:
+            traffic[names[k]] = {"bytes_per_unit": (s["hbm_read_bytes_x2"] + s["hbm_write_bytes"]) / units,
+                                 "source": f"profiles/{tag}_summary.json (FETCH_SIZE x2 + WRITE_SIZE, KiB->B), 1024 products "
+                                           "in 22 launches (46.5 per launch)"}
+    json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
