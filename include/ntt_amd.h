@@ -66,7 +66,8 @@ int ntt_ctx_create(const int *device_ids, int ndev, ntt_ctx **out_ctx);
 /* Destroy every plan made from a context BEFORE the context: a plan handle points into its context. */
 int ntt_ctx_destroy(ntt_ctx *ctx);
 /* Use an existing hipStream_t (passed as void*) for all work of this context; NULL restores the
- * context's own stream.  ntt_ctx_stream returns the stream in use (as void*). */
+ * context's own stream (to run on the null stream itself pass the handle (void*)1, hipStreamLegacy; the library then uses stream 0).
+ * ntt_ctx_stream returns the stream in use (as void*). */
 int ntt_ctx_set_stream(ntt_ctx *ctx, void *hip_stream);
 void *ntt_ctx_stream(ntt_ctx *ctx);
 int ntt_ctx_synchronize(ntt_ctx *ctx);

@@ -169,6 +169,14 @@ class Context:
     def set_stream(self, stream_ptr):
         _check(_lib.ntt_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
 
+    def use_torch_stream(self):
+        """Run this context's work on torch's current stream, so that torch ops, collectives and the library's
+        kernels are ordered by the stream alone.  torch's default stream is the null stream, whose handle 0 means
+        "back to the context's own stream" to ntt_ctx_set_stream: it is passed as hipStreamLegacy (handle 1)."""
+        import torch
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self.set_stream(s if s else 1)
+
     @property
     def stream(self):
         return _lib.ntt_ctx_stream(self._h)

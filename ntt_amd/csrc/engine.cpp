@@ -748,7 +748,10 @@ int ntt_ctx_set_stream(ntt_ctx *ctx, void *hip_stream)
 try {
     if (!ctx) return fail(NTT_ERR_INVALID, "null context");
     std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    // (void*)1 = hipStreamLegacy names the null stream; the runtime's own handling of that handle in
+    // hipEventRecord / hipStreamWaitEvent faults (ROCm 7.0 runtime bundled with PyTorch), its handle 0 does not
+    if (hip_stream == reinterpret_cast<void *>(1)) ctx->stream = nullptr;
+    else ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     ctx->cur = ctx->stream;
     return NTT_OK;
 }

@@ -81,7 +81,7 @@ def main(argv=None):
         # one stream for torch's collectives / fills and the library's kernels: the all-to-all's output is
         # ordered before the merge that reads it and the residue kernels before the exchange that sends them,
         # without a host synchronisation in between
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.use_torch_stream()
     if rank == 0:
         print(f"{world} ranks, one GPU each ({args.backend})" if on_gpu else
               f"{world} ranks on {min(world, ndev)} GPU(s) ({args.backend})", flush=True)
@@ -113,22 +113,12 @@ def main(argv=None):
                 a_op, b_op = (a, b) if on_gpu else (a.numpy().view(np.uint64), b.numpy().view(np.uint64))
             out_op = ab if on_gpu else ab.numpy().view(np.uint32 if p < (1 << 32) else np.uint64)
         if not single:
-            a_op, b_op = (a, b) if on_gpu else (a.numpy().view(np.uint64), b.numpy().view(np.uint64))
-
-            def residue_fn(k):                                   # the library overwrites all 2n-1 entries
-                r = torch.empty(2 * n - 1, dtype=torch.int32, device=device)
-                ctx.crt_residue_multiply(a_op, b_op, k, out=r if on_gpu else r.numpy().view(np.uint32))
-                return r                                         # on_gpu: queued on torch's stream (see above)
-
-            def merge_fn(rows, count):
-                m = torch.empty(count, dtype=torch.int64, device=device)
-                ctx.crt_merge(rows if on_gpu else [r.numpy().view(np.uint32) for r in rows], p,
-                              out=m if on_gpu else m.numpy().view(np.uint64), count=count)
-                return m
-
             if world == 1:                                       # all four primes and the merge on this rank
+                a_op, b_op = (a, b) if on_gpu else (a.numpy().view(np.uint64), b.numpy().view(np.uint64))
                 ab = torch.zeros(2 * n - 1, dtype=torch.int64, device=device)
                 crt_out = ab if on_gpu else ab.numpy().view(np.uint64)
+            else:                                                # buffers of the exchange allocated once per case
+                xchg = shard.CrtExchange(group, ctx, n, p, device=device)
 
         def epoch():
             nonlocal ab
@@ -140,7 +130,7 @@ def main(argv=None):
                 ctx.crt_multiply(a_op, b_op, p, out=crt_out)
                 ctx.synchronize()
             else:
-                ab = shard.crt_multiply_sharded(group, residue_fn, merge_fn, n, device=device)
+                ab = xchg.multiply(a, b)                       # residues -> all-to-all -> merge -> all-gather, one stream
                 if on_gpu:
                     torch.cuda.synchronize()
 

@@ -87,7 +87,7 @@ def crt_multiply_sharded(group, residue_fn, merge_fn, n, device="cpu"):
     Returns an int64 torch tensor [2n-1] (u64 bit pattern), identical on every rank.
     The tensors handed to merge_fn come out of all_to_all_single / .contiguous() on torch's CURRENT
     stream, and what residue_fn returns is sent from that stream: with device tensors the library must
-    run on the same stream (Context.set_stream(torch.cuda.current_stream().cuda_stream), as
+    run on the same stream (Context.use_torch_stream(), as
     ntt_amd.launch does) or the callbacks must synchronise both ways themselves -- the context's own
     stream is not ordered against torch's.
     """
@@ -156,3 +156,110 @@ def torch_all_to_all(group):
         group.dist.all_to_all_single(recv.view(-1), send.view(-1))
         return recv
     return a2a
+
+
+class CrtExchange:
+    """The sharded large-modulus product of crt_multiply_sharded for REPEATED calls at one size, with every
+    buffer preallocated and the whole epoch queued on one stream (reference: the epoch loop of
+    main-mpi.cc:706-802 with its gather-to-root :772-791 and merge-on-root :793-796).
+
+    * rank r owns primes partition(4, world, r) (main-mpi.cc:657-660); ``ntt_crt_residue_multiply`` writes the
+      residue product of owned prime slot j straight into ``send[j]`` -- a [world][sl] buffer whose row h is
+      the coefficient slice rank h merges, i.e. the product lands in exchange order (its zero tail padding is
+      written once, here);
+    * one ``all_to_all_single`` per prime slot (RCCL on device tensors) brings slice `rank` of every prime;
+      ``ntt_crt_merge`` turns the four slices into this rank's u64 slice; an all-gather into views of
+      ``full`` assembles the product on every rank.
+
+    With device tensors the context is switched to torch's current stream, so compute and collectives are
+    ordered by the stream alone: no host synchronisation inside an epoch, no allocation after construction
+    (``torch.cuda.memory_stats`` is flat across calls; tests/test_gpu_multiprocess.py).  The returned tensor
+    is a view of ``full`` and is overwritten by the next call.  With host tensors (gloo rehearsal on a
+    one-GPU box) the library stages through its own buffers and returns after its copies.
+    """
+
+    def __init__(self, group, ctx, n, p64, device="cpu"):
+        import torch
+        self.group, self.ctx, self.n, self.p64 = group, ctx, int(n), int(p64)
+        self.device = torch.device(device)
+        world = group.world
+        self.out_len = 2 * self.n - 1
+        self.sl = -(-self.out_len // world)
+        self.maxk = -(-4 // world)
+        self.start, self.count = partition(4, world, group.rank)
+        kw = dict(dtype=torch.int32, device=self.device)
+        self.send = [torch.zeros(world * self.sl, **kw) for _ in range(self.maxk)]
+        self.recv = [torch.zeros((world, self.sl), **kw) for _ in range(self.maxk)] if world > 1 else \
+                    [s.view(world, self.sl) for s in self.send]
+        self.mine = torch.zeros(self.sl, dtype=torch.int64, device=self.device)
+        self.full = torch.zeros(world * self.sl, dtype=torch.int64, device=self.device)
+        self.parts = list(self.full.view(world, self.sl).unbind(0))
+        if self.device.type == "cuda":
+            ctx.use_torch_stream()
+
+    def _arg(self, t):                                  # host tensors go in as numpy views (the library stages them)
+        return t if self.device.type == "cuda" else t.numpy()
+
+    def multiply(self, a, b):
+        """a, b: int64 tensors [n] (u64 bit patterns) on `device`; returns int64 [2n-1], identical on every rank."""
+        import numpy as np
+        g, dev = self.group, self.device.type == "cuda"
+        for j in range(self.count):
+            out = self.send[j] if dev else self.send[j].numpy().view(np.uint32)
+            self.ctx.crt_residue_multiply(a if dev else a.numpy().view(np.uint64), b if dev else b.numpy().view(np.uint64),
+                                          self.start + j, out=out)
+        if g.world > 1:
+            for j in range(self.maxk):
+                g.dist.all_to_all_single(self.recv[j].view(-1), self.send[j])
+        rows = [self.recv[k % self.maxk][k // self.maxk] for k in range(4)]     # prime k: rank k // maxk, slot k % maxk
+        self.ctx.crt_merge(rows if dev else [r.numpy().view(np.uint32) for r in rows], self.p64,
+                           out=self.mine if dev else self.mine.numpy().view(np.uint64), count=self.sl)
+        if g.world > 1:
+            g.dist.all_gather(self.parts, self.mine)
+            return self.full[:self.out_len]
+        return self.mine[:self.out_len]
+
+
+class DistExchange:
+    """dist_transform for repeated calls: the two all-to-alls of one split transform through two preallocated
+    ping-pong buffers (device tensors: RCCL on torch's current stream, which the context is switched to, so
+    the column pass and the exchanges are ordered by the stream alone; host exchange over gloo: two pinned-size
+    host mirrors).  ``forward`` leaves its input untouched; the result is a view of an internal buffer and is
+    overwritten by the next call."""
+
+    def __init__(self, group, ctx, dplan, on_device_exchange=True):
+        import torch
+        self.group, self.ctx, self.dp = group, ctx, dplan
+        self.world, self.S = dplan.world, dplan.local_length
+        self.buf = [torch.zeros(self.S, dtype=torch.int32, device="cuda") for _ in range(2)]
+        self.host = None
+        if not on_device_exchange and group.dist is not None:
+            self.host = [torch.zeros(self.S, dtype=torch.int32) for _ in range(2)]
+        ctx.use_torch_stream()
+
+    def _a2a(self, src, dst):
+        if self.group.dist is None:
+            dst.copy_(src)
+        elif self.host is None:
+            self.group.dist.all_to_all_single(dst, src)
+        else:
+            self.host[0].copy_(src)                    # D2H on torch's stream, complete on return
+            self.group.dist.all_to_all_single(self.host[1], self.host[0])
+            dst.copy_(self.host[1])
+
+    def forward(self, x_local):
+        a, b = self.buf
+        self._a2a(x_local, a)
+        self.dp.colpass(a, inverse=False)
+        self._a2a(a, b)
+        self.dp.local(b, inverse=False)
+        return b
+
+    def inverse(self, X_local):
+        a, b = self.buf
+        a.copy_(X_local)
+        self.dp.local(a, inverse=True)
+        self._a2a(a, b)
+        self.dp.colpass(b, inverse=True)
+        self._a2a(b, a)
+        return a

@@ -39,6 +39,11 @@ def main():
     full = shard.crt_multiply_sharded(g, residue_fn, merge_fn, n)
     want, _ = orc.poly_multiply_crt(a, b, p64, threads=2)
     ok = ok and bool(np.array_equal(full.numpy().view(np.uint64), want))
+    # the per-epoch form of the same exchange (preallocated buffers, products written in exchange order)
+    xchg = shard.CrtExchange(g, ctx, n, p64)
+    ta, tb = torch.from_numpy(a.view(np.int64).copy()), torch.from_numpy(b.view(np.int64).copy())
+    for _ in range(2):
+        ok = ok and bool(np.array_equal(xchg.multiply(ta, tb).numpy().view(np.uint64), want))
 
     # ---- one transform of length 2^16 split over the ranks: two all-to-alls around the GPU pieces
     p, lgL = 469762049, 16
@@ -68,6 +73,17 @@ def main():
     ok = ok and bool(np.array_equal(fwd.numpy().view(np.uint32), X[rank::G]))
     back = shard.dist_transform(G, rank, a2a, colpass, local, fwd, inverse=True)
     ok = ok and bool(np.array_equal(back.numpy().view(np.uint32), x[rank * S:(rank + 1) * S]))
+    # the same with preallocated ping-pong buffers (shard.DistExchange); exchanges through host mirrors over gloo
+    dx = shard.DistExchange(g, ctx, dp, on_device_exchange=False)
+    dmine = mine.cuda()
+    for _ in range(2):
+        f2 = dx.forward(dmine)
+        torch.cuda.synchronize()
+        ok = ok and bool(np.array_equal(f2.cpu().numpy().view(np.uint32), X[rank::G]))
+        b2 = dx.inverse(f2.clone())
+        torch.cuda.synchronize()
+        ok = ok and bool(np.array_equal(b2.cpu().numpy().view(np.uint32), x[rank * S:(rank + 1) * S]))
+    ctx.set_stream(None)
     dp.close()
 
     # ---- batch sharding as in bench.py: partition(), per-rank seeds, max over ranks

@@ -503,6 +503,20 @@ def test_crt_sharded_world1(nt, ctx):
     got = shard.crt_multiply_sharded(g, residue_fn, merge_fn, n, device="cuda")
     ctx.synchronize()
     assert np.array_equal(got.cpu().numpy().view(np.uint64), want)
+    # the per-epoch form: buffers owned by the exchange object, library on torch's stream, nothing allocated and
+    # no host synchronisation inside an epoch (main-mpi.cc:706-802 is the loop it serves)
+    xchg = shard.CrtExchange(g, ctx, n, p64, device="cuda")
+    try:
+        first = xchg.multiply(da, db).clone()
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_stats()["allocation.all.allocated"]
+        for _ in range(3):
+            out = xchg.multiply(da, db)
+        assert torch.cuda.memory_stats()["allocation.all.allocated"] == before
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), want) and torch.equal(out, first)
+    finally:
+        ctx.set_stream(None)                                      # the module's context goes back to its own stream
 
 
 def test_dist_transform_virtual_ranks(nt, ctx):
@@ -766,3 +780,35 @@ def test_caller_stream(nt):
     assert c.stream == own
     plan.close()
     c.close()
+
+
+def test_library_on_torch_stream(nt):
+    """Context.use_torch_stream(): torch's ops and the library's kernels queue on one stream (torch's default
+    stream is the null stream, handed over as hipStreamLegacy), so a product may consume a tensor torch is still
+    producing and torch may consume the product, with no host synchronisation in between -- the ordering
+    ntt_amd.launch and shard.CrtExchange rely on."""
+    import torch
+    c = nt.Context(0)
+    c.use_torch_stream()
+    n, batch, p = 65536, 24, 998244353
+    plan = c.plan(p, n, batch)
+    ref_ctx = nt.Context(0)                                  # its own stream, synchronised by hand: the reference
+    ref_plan = ref_ctx.plan(p, n, batch)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(9)
+    base = torch.randint(0, p, (batch, n), generator=gen, device="cuda", dtype=torch.int64)
+    other = torch.randint(0, p, (batch, n), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32)
+    out = torch.empty((batch, 2 * n - 1), dtype=torch.int32, device="cuda")
+    want = torch.empty_like(out)
+    for i in range(6):
+        a = ((base * (i + 3) + i) % p).to(torch.int32)       # queued on torch's stream, not waited for
+        plan.multiply(a, other, out=out, batch=batch)        # queued behind it
+        got = out.clone()                                    # torch reads the product behind the library's kernels
+        torch.cuda.synchronize()
+        ref_plan.multiply(a, other, out=want, batch=batch)
+        ref_ctx.synchronize()
+        assert torch.equal(got, want), i
+    plan.close()
+    ref_plan.close()
+    c.close()
+    ref_ctx.close()
