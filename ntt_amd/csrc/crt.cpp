@@ -8,6 +8,7 @@
 // the Garner/Horner kernel of kernels_misc.hip.
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -33,7 +34,7 @@ void crt_release(ntt_ctx *ctx)
         pl = nullptr;
     }
     w.ra.release(); w.rb.release(); w.res.release();
-    w.a64.release(); w.b64.release(); w.out64.release(); w.merge_in.release();
+    w.a64.release(); w.b64.release(); w.out64.release(); w.merge_in.release(); w.area.release();
     w.n = 0;
     w.batch = 0;
 }
@@ -123,6 +124,67 @@ try {
     uint32_t *ra = static_cast<uint32_t *>(w.ra.ptr), *rb = static_cast<uint32_t *>(w.rb.ptr);
     uint32_t *res = static_cast<uint32_t *>(w.res.ptr);
     const uint32_t *rows[4];
+    // A batch goes through in GROUPS, each group a chain of its own -- reduce, four residue products, merge -- and the
+    // groups alternate between the context's two stream lanes: the memory-bound reduce and merge sweeps of one group
+    // run beside the VALU-bound row kernels of the other instead of alone on the chip (reduce + merge were 180 of
+    // 873 us per 64 products; profiles/time_crt_r02.txt).  The intermediates of the transforms live in two work
+    // areas owned by the CRT workspace, one per lane, shared by the four primes of a group (they run in sequence).
+    const uint32_t L = w.plans[0]->wide ? w.plans[0]->wide->L : w.plans[0]->L;
+    const bool needs_area = w.plans[0]->logL > kRowLog && !w.plans[0]->fused && !w.plans[0]->wide;
+    if (batch >= 4 && ctx->nlanes > 1 && ctx->lane[1] && ctx->lane_limit != 1 && needs_area) {
+        static const int group_max = [] { const char *e = std::getenv("NTT_AMD_CRT_GROUP"); return e ? std::max(1, std::atoi(e)) : 32; }();
+        int ngroups = (batch + group_max - 1) / group_max;
+        if (ngroups & 1) ++ngroups;                        // the same number of groups on both lanes
+        const int G = (batch + ngroups - 1) / ngroups;
+        const size_t per_lane = 2 * (size_t)G * L;         // words: w0 and w1 of one lane
+        if ((rc = w.area.ensure(2 * per_lane * sizeof(uint32_t)))) return rc;
+        hipStream_t main_stream = ctx->stream;
+        HIP_TRY(hipEventRecord(ctx->fork_ev, main_stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->lane[1], ctx->fork_ev, 0));
+        {
+            struct Restore {
+                ntt_ctx *c;
+                hipStream_t s;
+                ~Restore() { c->stream = s; c->cur = s; }
+            } restore{ctx, main_stream};
+            int gi = 0;
+            for (int g0 = 0; g0 < batch && !rc; g0 += G, ++gi) {
+                const int gb = std::min(G, batch - g0), lane = gi & 1;
+                hipStream_t s = lane ? ctx->lane[1] : main_stream;
+                ctx->stream = s;
+                ctx->cur = s;
+                const size_t o = (size_t)g0 * n, cnt = (size_t)gb * n;
+                ctx->begin(K_CRT_REDUCE);
+                launch_crt_reduce_all(da + o, db + o, ra + o, rb + o, cnt, N, cc, s);
+                ctx->end();
+                uint32_t *base = static_cast<uint32_t *>(w.area.ptr) + lane * per_lane;
+                const WorkArea area{base, base + (size_t)G * L, G};
+                for (int k = 0; k < 4 && !rc; ++k) {
+                    rc = multiply_device_any(w.plans[k], ra + k * N + o, rb + k * N + o, res + k * out_len + (size_t)g0 * row_len,
+                                             row_len, gb, &area);
+                    rows[k] = res + k * out_len + (size_t)g0 * row_len;
+                }
+                ctx->cur = s;
+                ctx->begin(K_CRT_MERGE);
+                launch_crt_merge(rows, dout + (size_t)g0 * row_len, (size_t)gb * row_len, cc, s);
+                ctx->end();
+            }
+        }
+        // join even after a failure: the next call must not find the lanes unordered
+        const hipError_t je = hipEventRecord(ctx->lane_done[1], ctx->lane[1]);
+        const hipError_t we = je == hipSuccess ? hipStreamWaitEvent(main_stream, ctx->lane_done[1], 0) : je;
+        if (we != hipSuccess) (void)hipStreamSynchronize(ctx->lane[1]);
+        if (rc) return rc;
+        HIP_TRY(hipGetLastError());
+        if (int lrc_ = ntt::take_launch_error()) return lrc_;
+        if (!dev_o) {
+            HIP_TRY(hipMemcpyAsync(ab, dout, out_len * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        } else if (!dev_a || !dev_b) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        return NTT_OK;
+    }
     ctx->begin(K_CRT_REDUCE);                              // both operands, all four primes: one launch
     launch_crt_reduce_all(da, db, ra, rb, N, N, cc, ctx->stream);
     ctx->end();

@@ -371,13 +371,6 @@ static void small_pass(ntt_plan *pl, int mode, const uint32_t *a0, const uint32_
     cx->end();
 }
 
-// Where a multiply keeps the intermediates of its passes when they are not the plan's own work buffers:
-// room for `chunk` products (w0 / w1: chunk * L words each), one stream lane.
-struct WorkArea {
-    uint32_t *w0, *w1;
-    int chunk;
-};
-
 // a, b, ab: DEVICE pointers.  area == nullptr: the plan's work buffers and lanes.
 template <class MM>
 static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
@@ -493,10 +486,10 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
 }
 
 int multiply_device_any(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
-                        size_t ab_stride, int batch)
+                        size_t ab_stride, int batch, const WorkArea *area)
 {
-    const int rc = pl->kind == NTT_MODMUL_MONTGOMERY ? multiply_device<Mont32>(pl, a, b, ab, ab_stride, batch)
-                                                     : multiply_device<Barrett32>(pl, a, b, ab, ab_stride, batch);
+    const int rc = pl->kind == NTT_MODMUL_MONTGOMERY ? multiply_device<Mont32>(pl, a, b, ab, ab_stride, batch, area)
+                                                     : multiply_device<Barrett32>(pl, a, b, ab, ab_stride, batch, area);
     const int lrc = take_launch_error();                  // a dispatcher without a kernel for this shape launched nothing
     return rc ? rc : lrc;
 }

@@ -38,6 +38,7 @@ struct CrtWorkspace {
     int n = 0, batch = 0;                 // plans hold `batch` products of length n
     ntt_plan *plans[4] = {nullptr, nullptr, nullptr, nullptr};
     DeviceBuffer ra, rb, res, a64, b64, out64, merge_in;
+    DeviceBuffer area;                    // work areas of the grouped batch (crt.cpp): 2 lanes x 2 operands x group x L words
 };
 void crt_release(ntt_ctx *ctx);
 struct StreamState;                       // stream.cpp: ring of device slots + copy streams
@@ -47,9 +48,15 @@ const char *last_error_cstr();
 int take_launch_error();
 bool is_device_ptr(const void *p);
 
-// device-pointer entry used by the CRT path (caller holds ctx->mu)
+// Where a multiply keeps the intermediates of its passes when they are not the plan's own work buffers:
+// room for `chunk` products (w0 / w1: chunk * L words each); the multiply then runs on ONE stream (ctx->stream).
+struct WorkArea {
+    uint32_t *w0, *w1;
+    int chunk;
+};
+// device-pointer entry used by the CRT path (caller holds ctx->mu); area == nullptr: the plan's buffers and lanes
 int multiply_device_any(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
-                        size_t ab_stride, int batch);
+                        size_t ab_stride, int batch, const WorkArea *area = nullptr);
 
 }  // namespace ntt
 

@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, R + '/tests')
 import numpy as np, torch, ntt_amd
 p64, n, B = 1337006139375617, 131072, 64
 ctx = ntt_amd.Context(0)
