@@ -365,31 +365,6 @@ static std::mutex g_mu;
 static constexpr size_t kMaxCachedPlans = 8;
 static std::vector<std::array<uint64_t, 3>> g_plan_lru;            // most recently used last
 
-// The harness passes the same static arrays on every call (main-montgomery.cc:297: `int a[300000], b[300000],
-// ab[300000]`).  Page-locking them the first time they are seen lets the three copies of a call run as plain
-// DMA instead of going through the runtime's pageable staging.  An array is registered when the same (pointer,
-// size) arrives for the second time -- one-shot callers with transient arrays are left alone -- and the
-// registration is kept (a bounded number of ranges) and never repeated.  NTT_AMD_PIN_CALLER=0 turns it off.  A range that cannot be registered (already
-// registered by the caller, not page-lockable) simply stays pageable.
-struct PinnedRange { const void *ptr; size_t bytes; int seen; bool ok; };
-static std::vector<PinnedRange> g_pinned;
-static constexpr size_t kMaxPinnedRanges = 12;
-static void pin_caller_array(const void *ptr, size_t bytes)
-{
-    static const bool enabled = [] { const char *e = std::getenv("NTT_AMD_PIN_CALLER"); return !(e && e[0] == '0'); }();
-    if (!enabled || bytes < (64u << 10)) return;                 // small arrays: the registration costs more than it saves
-    for (auto &r : g_pinned) {
-        if (r.ptr != ptr || r.bytes != bytes) continue;
-        if (r.seen++ == 1) {                                     // second sight of the same array: a repeat caller
-            const hipError_t e = hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault);
-            if (e != hipSuccess) (void)hipGetLastError();
-            r.ok = e == hipSuccess;
-        }
-        return;
-    }
-    if (g_pinned.size() < kMaxPinnedRanges) g_pinned.push_back({ptr, bytes, 1, false});
-}
-
 extern "C" void poly_multiply(int *a, int *b, int *ab, int n, int p)
 try {
     auto die = [](const char *what) {
@@ -426,11 +401,6 @@ try {
                 if (g_plan_lru[i] == key) { g_plan_lru.erase(g_plan_lru.begin() + (long)i); break; }
         }
         g_plan_lru.push_back(key);
-        if (hipSetDevice(g_ctx->device) == hipSuccess) {
-            pin_caller_array(a, (size_t)n * sizeof(int));
-            pin_caller_array(b, (size_t)n * sizeof(int));
-            pin_caller_array(ab, ((size_t)2 * n - 1) * sizeof(int));
-        }
     }
     // int and uint32_t share their representation for values in [0, p), p < 2^31
     if (ntt_poly_multiply_batched(pl, reinterpret_cast<const uint32_t *>(a), reinterpret_cast<const uint32_t *>(b),
