@@ -46,6 +46,14 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB
 # issues over 2 cycles (v_add/v_sub/logic) or 4 (v_mul_lo/hi, v_mad_u64_u32, v_min, shifts:
 # profiles/ubench_intmul_r01.txt, ubench_valu2_r01.txt)
 SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
+# measured floors of the two resources the pipeline shares (one MI355X, round 2):
+#   profiles/ubench_mix_r02.txt          the butterfly's own instruction mix (add, borrow-subtract, select, sub, 3
+#                                        multiply instructions) in a register-only loop, 7 x 4 waves per CU:
+#                                        40.6 T lane-op/s at an in-kernel clock of 2.35 GHz
+#   profiles/ubench_pipeline_mem_r02.txt three kernels that move the pipeline's bytes with its access patterns and
+#                                        hand-off buffers and compute nothing: 1.24 us per product (48 per launch, 2 lanes)
+MEASURED_MIX_PEAK_TLANEOPS = 40.6
+MEASURED_TRAFFIC_FLOOR_US = 1.244
 
 
 def splitmix64(seed, count):
@@ -160,7 +168,7 @@ def kernel_source_stamp():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "ntt_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp", ".cpp")):
+        if f.endswith((".hip", ".hpp")):            # the device code: kernels and the headers they include
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
@@ -393,6 +401,10 @@ def main(argv=None):
                     "unit": "T lane-op/s", "floor_us_per_product": floor_us,
                     "frac": floor_us / (1e6 * world / value),
                     "per_kernel_issue_cycles": {k: v["issue_cycles_per_product"] for k, v in vj["kernels"].items()},
+                    "measured_mix_peak": MEASURED_MIX_PEAK_TLANEOPS,
+                    "frac_of_measured_mix_peak": lane_ops * value / world / 1e12 / MEASURED_MIX_PEAK_TLANEOPS,
+                    "floor_us_at_measured_mix_peak": lane_ops / MEASURED_MIX_PEAK_TLANEOPS / 1e6,
+                    "traffic_floor_us_per_product": MEASURED_TRAFFIC_FLOOR_US,
                     "measured_on_build": vj.get("_build"), "same_build": vj.get("_build") == stamp,
                     "note": "peak = this instruction mix at 2 / 4 issue cycles per wave64 instruction on 256 CUs x 4 SIMDs at 2.4 GHz"}
         out = {

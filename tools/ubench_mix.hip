@@ -1,0 +1,108 @@
+// ubench_mix.hip -- what the VALU sustains on the butterfly's own instruction mix, with no memory traffic.
+// Every thread keeps 16 residues in registers and runs radix-2 butterflies on them in a long loop:
+//   mix   : the nontrivial lazy butterfly of the row kernel -- v_add, v_subrev_co, v_cndmask (sum, conditional
+//           subtract of 2p), v_sub, v_mad_i64_i32, v_mul_lo_u32, v_mad_u64_u32 ((u - v) * w, Montgomery REDC): 7
+//           instructions, 3 of them half rate
+//   mul   : the three multiply instructions of a modular multiplication only
+//   addsub: the four full-rate instructions only
+// Prints lane-ops per second, cycles per wave instruction per SIMD at the nominal 2.4 GHz, and the clock the chip
+// actually held inside the kernel (s_memtime / s_memrealtime), after a warm-up long enough for the power
+// controller to settle.  Build: hipcc -O3 --offload-arch=gfx950 tools/ubench_mix.hip -o tools/ubench_mix
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+struct P { uint32_t p, p2, nprime, w; };
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k(uint32_t *out, uint64_t *clk, P c, int iters)
+{
+    uint32_t x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = threadIdx.x * 2654435761u + i * 40503u + blockIdx.x;
+    const uint64_t C = (uint64_t)c.p2 * c.w;
+    const uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int half = 8 >> s;
+#pragma unroll
+            for (int b = 0; b < 16; b += 2 * half)
+#pragma unroll
+                for (int j = 0; j < half; ++j) {
+                    uint32_t u = x[b + j], v = x[b + j + half];
+                    if (MODE != 1) {                                  // sum, conditional subtract
+                        uint32_t t, r, sum = u + v;
+                        asm volatile("v_subrev_co_u32 %0, vcc, %2, %3\n\tv_cndmask_b32 %1, %0, %3, vcc"
+                                     : "=&v"(t), "=v"(r) : "s"(c.p2), "v"(sum) : "vcc");
+                        x[b + j] = r;
+                    }
+                    if (MODE == 2) {
+                        x[b + j + half] = u - v;
+                    } else {                                          // (u - v) * w, lazy Montgomery
+                        uint64_t T, carry;
+                        const uint32_t d = MODE == 1 ? u : u - v;
+                        if (MODE == 3) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(T) : "v"(d), "v"(c.w + (uint32_t)j), "s"(C) : "vcc");
+                        else asm volatile("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(T), "=s"(carry) : "v"(d), "v"(c.w + (uint32_t)j), "s"(C));
+                        const uint32_t q = (uint32_t)T * c.nprime;
+                        const uint64_t t2 = T + (uint64_t)q * c.p;
+                        x[b + j + half] = (uint32_t)(t2 >> 32);
+                        if (MODE == 1) x[b + j] = x[b + j + half] ^ v;
+                    }
+                }
+        }
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc ^= x[i];
+    if (acc == 0x12345u) out[0] = acc;                                // keeps the arithmetic live
+    if (threadIdx.x == 0 && blockIdx.x < 64) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+template <int MODE>
+static void run(const char *name, double insts_per_iter)
+{
+    uint32_t *out;
+    uint64_t *clk, h[128];
+    CK(hipMalloc(&out, 64));
+    CK(hipMalloc(&clk, sizeof(h)));
+    const P c{998244353u, 2 * 998244353u, 998244351u, 299560064u};
+    const int blocks = 256 * 7, iters = 4000;                       // 7 workgroups of 4 waves per CU, as the row kernel
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int w = 0; w < 40; ++w) k<MODE><<<blocks, 256>>>(out, clk, c, iters);   // ~1-2 s of load before the timed launches
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    const int reps = 10;
+    for (int r = 0; r < reps; ++r) k<MODE><<<blocks, 256>>>(out, clk, c, iters);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost));
+    double ghz = 0;
+    for (int i = 0; i < 64; ++i) ghz += (double)h[2 * i] / (double)h[2 * i + 1] * 0.1;   // memrealtime ticks at 100 MHz
+    ghz /= 64;
+    const double wave_insts = (double)reps * blocks * 4 * iters * insts_per_iter;        // 4 waves per block
+    const double lane_ops = wave_insts * 64;
+    const double sec = ms * 1e-3;
+    printf("%-7s %6.1f T lane-op/s  %5.2f cycles per wave-instr per SIMD at 2.4 GHz  %5.2f at the in-kernel clock %.2f GHz\n", name,
+           lane_ops / sec / 1e12, sec * 2.4e9 * 1024 / wave_insts, sec * ghz * 1e9 * 1024 / wave_insts, ghz);
+}
+
+int main()
+{
+    // per iteration: 4 stages x 8 butterflies
+    run<0>("mix", 32 * 7.0);
+    run<1>("mul", 32 * 4.0);      // mad_i64, mul_lo, mad_u64 + one xor
+    run<2>("addsub", 32 * 4.0);   // add, subrev_co, cndmask, sub
+    run<0>("mix", 32 * 7.0);
+    run<3>("mix-vcc", 32 * 7.0);  // the same with the multiply-add's unused carry-out sent to vcc instead of an SGPR pair
+    return 0;
+}

@@ -45,7 +45,7 @@ KERNELS = {
 def source_stamp():
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)):
-        if f.endswith((".hip", ".hpp", ".cpp")):
+        if f.endswith((".hip", ".hpp")):            # the device code: kernels and the headers they include
             h.update(f.encode())
             h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:16]
