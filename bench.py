@@ -359,16 +359,13 @@ def main(argv=None):
         ctx1.close()
 
     rc = 0
-    if rank == 0:
+    if rank == 0 and args.no_kernel_timing:         # sweeps (tools/): the rate only
+        print(json.dumps({"value": world * B * args.steps / elapsed, "n_gpus": world,
+                          "ms_per_step": 1e3 * elapsed / args.steps, "chunk": args.chunk}), flush=True)
+    elif rank == 0:
         units = world * B * args.steps
         value = units / elapsed
         alg_bytes = 16 * n - 4                      # read a, read b, write ab
-        if args.no_kernel_timing:
-            print(json.dumps({"value": value, "ms_per_step": 1e3 * elapsed / args.steps, "chunk": args.chunk}), flush=True)
-            plan.close()
-            ctx.close()
-            group.close()
-            return 0
         # dominant kernel = largest share of device time in the timed region
         name, (tot_ms, launches) = max(((k, v) for k, v in ktimes.items() if v[1] > 0),
                                        key=lambda kv: kv[1][0])
@@ -439,6 +436,7 @@ def main(argv=None):
             out["cpu_baseline"] = cpu_baseline(n, p, args.cpu_seconds, gpu_row0)
         print(json.dumps(out), flush=True)
 
+    barrier()                       # rank 0 ran the one-lane table meanwhile: every rank leaves the group together
     plan.close()
     ctx.close()
     group.close()
