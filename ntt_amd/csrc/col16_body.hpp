@@ -8,9 +8,14 @@ namespace ntt {
 
 // Body of the LDS-staged column pass for one tile: `bx` = tile index within the row (blockIdx.x
 // of the stand-alone kernel), `by` = batch row, `op` = operand.  `lds` holds N1 * C words (4096; 8192 / 16384 for N1 = 128 / 256).
-template <class MM, bool LAZY, int LOGR, bool INVERSE, bool HALF>
-__device__ __forceinline__ void col16_body(const ColArgs<MM> &a, const ModParams &m, uint32_t *lds,
-                                           const uint32_t bx, const uint32_t by, const int op)
+// `Args` is ColArgs<MM> or any struct with the same field names (the CRT kernel passes a slimmer one);
+// `sink(idx, row, v)` receives output `idx` = j * R + kr of this thread (a compile-time constant after
+// unrolling), which is row `row` of the thread's column: the stand-alone kernel stores it, the fused CRT kernel
+// keeps it in registers.  `rout` / the element offset of (row, column) are the sink's business.
+template <class MM, bool LAZY, int LOGR, bool INVERSE, bool HALF, class Args, class Sink>
+__device__ __forceinline__ void col16_body_sink(const Args &a, const ModParams &m, uint32_t *lds,
+                                                const uint32_t bx, const uint32_t by, const int op, const bool canon,
+                                                Sink &&sink)
 {
     using O = Ops<MM, LAZY>;
     using tw_t = typename MM::tw_t;
@@ -28,7 +33,6 @@ __device__ __forceinline__ void col16_body(const ColArgs<MM> &a, const ModParams
     const uint32_t base = ((c >> a.logS) << a.logM) + i2;          // blk * M + i2
     // descriptors of this batch row: the range check gives zero padding (in_len) and the output cut
     const bufrsrc_t rin = make_buf(a.in[op] + (size_t)by * a.in_stride, a.in_len * 4u);
-    const bufrsrc_t rout = make_buf(a.out[op] + (size_t)by * a.out_stride, a.out_len * 4u);
     const bufrsrc_t rtw = make_buf(a.tw, (uint32_t)sizeof(tw_t) << a.logM);
     const uint32_t voff = base * 4u;
     const uint32_t twoff = i2 * (uint32_t)sizeof(tw_t);
@@ -96,13 +100,26 @@ __device__ __forceinline__ void col16_body(const ColArgs<MM> &a, const ModParams
                     else
                         v = O::canon(O::tighten(v, m), m);
                 }
-                if constexpr (CANON && INVERSE) buf_store_nt(v, rout, voff + (row << rowsh), 0);
-                else buf_store(v, rout, voff + (row << rowsh), 0);
+                sink(std::integral_constant<bool, CANON>{}, j * R + kr, voff + (row << rowsh), v);
             }
         }
     };
-    if (a.canon) pass2(std::true_type{});
+    if (canon) pass2(std::true_type{});
     else pass2(std::false_type{});
+}
+
+// The stand-alone form: every output is stored (streaming stores for the canonical final inverse pass: the
+// caller's result is never read back).
+template <class MM, bool LAZY, int LOGR, bool INVERSE, bool HALF>
+__device__ __forceinline__ void col16_body(const ColArgs<MM> &a, const ModParams &m, uint32_t *lds,
+                                           const uint32_t bx, const uint32_t by, const int op)
+{
+    const bufrsrc_t rout = make_buf(a.out[op] + (size_t)by * a.out_stride, a.out_len * 4u);
+    col16_body_sink<MM, LAZY, LOGR, INVERSE, HALF>(a, m, lds, bx, by, op, a.canon != 0,
+        [&](auto canon_tag, int, uint32_t byte_off, uint32_t v) {
+            if constexpr (decltype(canon_tag)::value && INVERSE) buf_store_nt(v, rout, byte_off, 0);
+            else buf_store(v, rout, byte_off, 0);
+        });
 }
 
 

@@ -136,7 +136,18 @@ try {
         int ngroups = (batch + group_max - 1) / group_max;
         if (ngroups & 1) ++ngroups;                        // the same number of groups on both lanes
         const int G = (batch + ngroups - 1) / ngroups;
-        const size_t per_lane = 2 * (size_t)G * L;         // words: w0 and w1 of one lane
+        // Fused tail (kernels_crt.hip): when the outermost column level of the four plans is one the LDS-staged kernel
+        // has for 32 or 64 points (L = 2^17, 2^18), the residue products stop in front of their last inverse column
+        // pass, each prime's row output stays in a work array of its own, and ONE kernel runs that pass for the four
+        // primes and merges -- the residues never travel through memory.  NTT_AMD_CRT_FUSE=0 keeps the separate kernels.
+        static const bool fuse_ok = [] { const char *e = std::getenv("NTT_AMD_CRT_FUSE"); return !(e && e[0] == '0'); }();
+        bool fuse = fuse_ok;
+        for (int k = 0; k < 4; ++k) {
+            const ntt_plan *pk = w.plans[k];
+            fuse = fuse && pk->kind == NTT_MODMUL_MONTGOMERY && pk->nlevels >= 1 && (pk->level_log[0] == 5 || pk->level_log[0] == 6) &&
+                   pk->L == L && pk->tw_in_inv[0].size() >= 64 * sizeof(uint32_t);
+        }
+        const size_t per_lane = (fuse ? 5 : 2) * (size_t)G * L;   // words: w1 and w0 (one w0 per prime when fused)
         if ((rc = w.area.ensure(2 * per_lane * sizeof(uint32_t)))) return rc;
         hipStream_t main_stream = ctx->stream;
         HIP_TRY(hipEventRecord(ctx->fork_ev, main_stream));
@@ -158,15 +169,42 @@ try {
                 launch_crt_reduce_all(da + o, db + o, ra + o, rb + o, cnt, N, cc, s);
                 ctx->end();
                 uint32_t *base = static_cast<uint32_t *>(w.area.ptr) + lane * per_lane;
-                const WorkArea area{base, base + (size_t)G * L, G};
                 for (int k = 0; k < 4 && !rc; ++k) {
+                    WorkArea area{base + (size_t)(fuse ? 1 + k : 1) * G * L, base, G};       // w1 (operand b) is shared
+                    area.stop_before_outer_inverse = fuse;
                     rc = multiply_device_any(w.plans[k], ra + k * N + o, rb + k * N + o, res + k * out_len + (size_t)g0 * row_len,
                                              row_len, gb, &area);
                     rows[k] = res + k * out_len + (size_t)g0 * row_len;
                 }
+                if (rc) break;
                 ctx->cur = s;
                 ctx->begin(K_CRT_MERGE);
-                launch_crt_merge(rows, dout + (size_t)g0 * row_len, (size_t)gb * row_len, cc, s);
+                if (fuse) {
+                    CrtInvArgs ia{};
+                    for (int k = 0; k < 4; ++k) {
+                        const ntt_plan *pk = w.plans[k];
+                        CrtInvPrime &ip = ia.prime[k];
+                        ip.in[0] = base + (size_t)(1 + k) * G * L;
+                        ip.in_stride = L;
+                        ip.in_len = L;
+                        ip.logM = pk->level_logM[0];
+                        ip.logS = pk->level_logM[0] - pk->level_log[0];
+                        ip.tw = static_cast<const uint32_t *>(pk->tw_inv[0]);
+                        ip.use_scale0 = pk->nlevels == 1 ? 1 : 0;
+                        std::memcpy(&ip.scale0, pk->scale_mul.data(), sizeof(ip.scale0));
+                        std::memcpy(&ip.roots, pk->iroots.data(), sizeof(ip.roots));
+                        std::memcpy(ip.tw_in, pk->tw_in_inv[0].data(), sizeof(ip.tw_in));
+                        ip.twist = nullptr;
+                        ia.mp[k] = pk->mp;
+                    }
+                    ia.cc = cc;
+                    ia.out = dout + (size_t)g0 * row_len;
+                    ia.out_stride = row_len;
+                    ia.out_len = (uint32_t)row_len;
+                    launch_crt_colinv_merge(w.plans[0]->level_log[0], ia, L >> w.plans[0]->level_log[0], (unsigned)gb, s);
+                } else {
+                    launch_crt_merge(rows, dout + (size_t)g0 * row_len, (size_t)gb * row_len, cc, s);
+                }
                 ctx->end();
             }
         }

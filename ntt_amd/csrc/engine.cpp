@@ -479,6 +479,7 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
         for (int j = m - 1; j >= 1; --j)
             col_pass<MM>(pl, j, true, false, w0, nullptr, w0, nullptr, L, L, L, L, pl->tw_inv[j],
                          j == m - 1, pl->scale_mul, false, cb, 1);
+        if (area && area->stop_before_outer_inverse) continue;
         col_pass<MM>(pl, 0, true, false, w0, nullptr, ab + (size_t)c0 * ab_stride, nullptr, L, ab_stride,
                      L, out_len, pl->tw_inv[0], m == 1, pl->scale_mul, true, cb, 1, neg ? pl->twist_inv : nullptr);
     }

@@ -53,6 +53,9 @@ bool is_device_ptr(const void *p);
 struct WorkArea {
     uint32_t *w0, *w1;
     int chunk;
+    // true: stop in front of the outermost inverse column pass -- w0 then holds, per product, the input of that pass
+    // (the CRT path runs it for four primes at once, fused with the merge: kernels_crt.hip); `ab` is not written
+    bool stop_before_outer_inverse = false;
 };
 // device-pointer entry used by the CRT path (caller holds ctx->mu); area == nullptr: the plan's buffers and lanes
 int multiply_device_any(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,

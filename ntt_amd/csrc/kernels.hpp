@@ -150,6 +150,31 @@ struct PermTileArgs {
 };
 void launch_permute_tiled(const PermTileArgs &pa, unsigned batch, hipStream_t s);
 
+// The last inverse column pass of the four residue products + the merge in one kernel (kernels_crt.hip).
+// One of these per prime: the fields col16_body reads from ColArgs, with only the 64 inner twiddles that a level of
+// 32 or 64 points uses, so that four of them fit the kernel-argument segment (L = 2^17 and 2^18; other shapes
+// keep the separate kernels)
+struct CrtInvPrime {
+    const uint32_t *in[1];               // this prime's row-pass output, [batch][L]
+    size_t in_stride;
+    uint32_t in_len;
+    int logM, logS;
+    const uint32_t *tw;                  // [N1][S] inverse 4-step twiddles (Montgomery form)
+    uint32_t scale0;                     // multiplier of row 0 (carries L^-1 R when the plan has one column level)
+    int use_scale0;
+    Roots64<Mont32> roots;               // inverse roots
+    uint32_t tw_in[64];
+    const uint32_t *twist;               // always nullptr here (linear products)
+};
+struct CrtInvArgs {
+    CrtInvPrime prime[4];
+    ModParams mp[4];
+    CrtConsts cc;
+    uint64_t *out;                       // [batch][out_stride] u64
+    size_t out_stride;
+    uint32_t out_len;                    // 2n - 1
+};
+bool launch_crt_colinv_merge(int logN1, const CrtInvArgs &a, unsigned cols_per_row, unsigned batch, hipStream_t s);
 void launch_crt_reduce(const uint64_t *x, uint32_t *out, size_t n, const CrtPrime &c, hipStream_t s);
 void launch_crt_reduce_all(const uint64_t *a, const uint64_t *b, uint32_t *ra, uint32_t *rb, size_t n,
                            size_t stride, const CrtConsts &cc, hipStream_t s);

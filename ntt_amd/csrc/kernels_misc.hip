@@ -1,4 +1,5 @@
 // kernels_misc.hip -- small-length transforms, order permutation and the CRT kernels, gfx950.
+#include "crt_device.hpp"
 #include "device_ntt.hpp"
 
 namespace ntt {
@@ -197,11 +198,6 @@ void launch_permute_tiled(const PermTileArgs &pa, unsigned batch, hipStream_t s)
 // Garner's mixed-radix form with 32-bit Shoup multiplications followed by a Horner evaluation
 // mod p64 with 64-bit Montgomery multiplications -- no 128-bit division, no MFMA.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t red32(uint32_t x, const CrtPrime &c)    // x mod m, any u32 x
-{
-    return csub(Barrett32::mul_tw(x, c.one, c.mp), c.mp.p);
-}
-
 __global__ void __launch_bounds__(256) crt_reduce_kernel(const uint64_t *__restrict__ x,
                                                          uint32_t *__restrict__ out, size_t n,
                                                          const CrtPrime c)
@@ -248,23 +244,6 @@ void launch_crt_reduce(const uint64_t *x, uint32_t *out, size_t n, const CrtPrim
     hipLaunchKernelGGL(crt_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out, n, c);
 }
 
-// (acc - v) * inv mod m_j, acc in [0, m_j), v any u32
-__device__ __forceinline__ uint32_t garner_step(uint32_t acc, uint32_t v, Barrett32::tw_t inv,
-                                                const CrtPrime &c)
-{
-    const uint32_t d = acc - red32(v, c) + c.mp.p;                  // (0, 2 m_j)
-    return csub(Barrett32::mul_tw(d, inv, c.mp), c.mp.p);
-}
-
-__device__ __forceinline__ uint64_t mont64_mul(uint64_t a, uint64_t b, const CrtConsts &cc)
-{
-    // REDC(a*b) with R = 2^64; a*b < p64 * 2^64, p64 < 2^63
-    const uint64_t lo = a * b, hi = __umul64hi(a, b);
-    const uint64_t q = lo * cc.nprime64;
-    uint64_t t = hi + __umul64hi(q, cc.p64) + (lo != 0 ? 1u : 0u);   // low words cancel to 0 or 2^64
-    return t >= cc.p64 ? t - cc.p64 : t;
-}
-
 __global__ void __launch_bounds__(256) crt_merge_kernel(const uint32_t *__restrict__ r0,
                                                         const uint32_t *__restrict__ r1,
                                                         const uint32_t *__restrict__ r2,
@@ -274,27 +253,7 @@ __global__ void __launch_bounds__(256) crt_merge_kernel(const uint32_t *__restri
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    // Garner: x = v0 + m0 * (v1 + m1 * (v2 + m2 * v3)), v_j in [0, m_j)
-    const uint32_t v0 = r0[i];
-    const uint32_t v1 = garner_step(r1[i], v0, cc.inv[0][1], cc.prime[1]);
-    uint32_t v2 = garner_step(r2[i], v0, cc.inv[0][2], cc.prime[2]);
-    v2 = garner_step(v2, v1, cc.inv[1][2], cc.prime[2]);
-    uint32_t v3 = garner_step(r3[i], v0, cc.inv[0][3], cc.prime[3]);
-    v3 = garner_step(v3, v1, cc.inv[1][3], cc.prime[3]);
-    v3 = garner_step(v3, v2, cc.inv[2][3], cc.prime[3]);
-    // Horner mod p64; plain value times Montgomery-form constant = plain value
-    const uint64_t p = cc.p64;
-    auto addmod = [p](uint64_t x, uint32_t v) {
-        uint64_t vv = v;
-        if (vv >= p) vv %= p;                                       // only when p64 < 2^31
-        const uint64_t s = x + vv;
-        return s >= p ? s - p : s;
-    };
-    uint64_t acc = addmod(0, v3);
-    acc = addmod(mont64_mul(acc, cc.mR[2], cc), v2);
-    acc = addmod(mont64_mul(acc, cc.mR[1], cc), v1);
-    acc = addmod(mont64_mul(acc, cc.mR[0], cc), v0);
-    out[i] = acc;
+    out[i] = crt_merge_value(r0[i], r1[i], r2[i], r3[i], cc);
 }
 
 void launch_crt_merge(const uint32_t *const res[4], uint64_t *out, size_t n, const CrtConsts &cc,

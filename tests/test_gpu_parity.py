@@ -812,3 +812,31 @@ def test_library_on_torch_stream(nt):
     ref_plan.close()
     c.close()
     ref_ctx.close()
+
+
+@pytest.mark.parametrize("n", [40000, 70000, 131072])
+def test_crt_batched_fused_tail(ctx, n):
+    """ntt_crt_multiply_batched at L = 2^17 / 2^18 with batch >= 4: groups on two lanes, the last inverse column pass of
+    the four primes and the merge in one kernel (kernels_crt.hip).  Every row against the single-product call (separate
+    kernels), rows 0 and last against the CRT oracle (main-openmp.cc:693-711); extreme operands in row 0."""
+    import torch
+    p64, batch = 1337006139375617, 7
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, p64, size=(batch, n), dtype=np.uint64)
+    b = rng.integers(0, p64, size=(batch, n), dtype=np.uint64)
+    a[0, :] = p64 - 1
+    b[0, :] = p64 - 1
+    da = torch.from_numpy(a.view(np.int64)).cuda()
+    db = torch.from_numpy(b.view(np.int64)).cuda()
+    out = torch.full((batch, 2 * n - 1), -1, dtype=torch.int64, device="cuda")
+    ctx.crt_multiply_batched(da, db, p64, out=out)
+    ctx.synchronize()
+    got = out.cpu().numpy().view(np.uint64)
+    for r in range(batch):
+        assert np.array_equal(got[r], ctx.crt_multiply(a[r], b[r], p64)), r
+    for r in (0, batch - 1):
+        want, _ = orc.poly_multiply_crt(a[r], b[r], p64, threads=4)
+        assert np.array_equal(got[r], want), r
+    # a second, smaller batch through the cached workspace, host arrays this time
+    got2 = ctx.crt_multiply_batched(a[2:6].copy(), b[2:6].copy(), p64)
+    assert np.array_equal(got2, got[2:6])
