@@ -147,6 +147,10 @@ try {
             fuse = fuse && pk->kind == NTT_MODMUL_MONTGOMERY && pk->nlevels >= 1 && (pk->level_log[0] == 5 || pk->level_log[0] == 6) &&
                    pk->L == L && pk->tw_in_inv[0].size() >= 64 * sizeof(uint32_t);
         }
+        // Fused head: the same shapes read the caller's u64 operands in the first forward column pass of every prime and
+        // reduce them there (col_kernel<..., U64IN>), so the reduce sweep and its residue arrays drop out as well.
+        bool fuse_in = fuse;
+        for (int k = 0; k < 4; ++k) fuse_in = fuse_in && !w.plans[k]->col16_fwd;
         const size_t per_lane = (fuse ? 5 : 2) * (size_t)G * L;   // words: w1 and w0 (one w0 per prime when fused)
         if ((rc = w.area.ensure(2 * per_lane * sizeof(uint32_t)))) return rc;
         hipStream_t main_stream = ctx->stream;
@@ -165,14 +169,19 @@ try {
                 ctx->stream = s;
                 ctx->cur = s;
                 const size_t o = (size_t)g0 * n, cnt = (size_t)gb * n;
-                ctx->begin(K_CRT_REDUCE);
-                launch_crt_reduce_all(da + o, db + o, ra + o, rb + o, cnt, N, cc, s);
-                ctx->end();
+                if (!fuse_in) {
+                    ctx->begin(K_CRT_REDUCE);
+                    launch_crt_reduce_all(da + o, db + o, ra + o, rb + o, cnt, N, cc, s);
+                    ctx->end();
+                }
                 uint32_t *base = static_cast<uint32_t *>(w.area.ptr) + lane * per_lane;
                 for (int k = 0; k < 4 && !rc; ++k) {
                     WorkArea area{base + (size_t)(fuse ? 1 + k : 1) * G * L, base, G};       // w1 (operand b) is shared
                     area.stop_before_outer_inverse = fuse;
-                    rc = multiply_device_any(w.plans[k], ra + k * N + o, rb + k * N + o, res + k * out_len + (size_t)g0 * row_len,
+                    area.u64_in = fuse_in ? &cc.prime[k] : nullptr;
+                    const uint32_t *pa = fuse_in ? reinterpret_cast<const uint32_t *>(da + o) : ra + k * N + o;
+                    const uint32_t *pb = fuse_in ? reinterpret_cast<const uint32_t *>(db + o) : rb + k * N + o;
+                    rc = multiply_device_any(w.plans[k], pa, pb, res + k * out_len + (size_t)g0 * row_len,
                                              row_len, gb, &area);
                     rows[k] = res + k * out_len + (size_t)g0 * row_len;
                 }

@@ -469,6 +469,22 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
         const uint32_t *ca = a + (size_t)c0 * n, *cbp = b + (size_t)c0 * n;
         // forward column levels (both operands per launch); level 0 reads the caller's arrays with
         // implicit zero padding (n <= L/2: the upper half of every column is zero)
+        if (area && area->u64_in) {                          // CRT path: u64 operands, reduced by the pass itself
+            if constexpr (MM::kMontgomery) {
+                const uint64_t *a64 = reinterpret_cast<const uint64_t *>(a) + (size_t)c0 * n;
+                const uint64_t *b64 = reinterpret_cast<const uint64_t *>(b) + (size_t)c0 * n;
+                ColArgs<MM> ca64 = fill_col<MM>(pl, 0, false, reinterpret_cast<const uint32_t *>(a64), reinterpret_cast<const uint32_t *>(b64),
+                                                w0, w1, n, L, n, L, pl->tw_fwd[0], false, {}, false);
+                ca64.in_one = area->u64_in->one;
+                ca64.in_two32 = area->u64_in->two32;
+                cx->begin(K_COL_FWD);
+                const bool ok = launch_col_u64in(pl->lazy, pl->level_log[0], &ca64, pl->mp, pl->L >> pl->level_log[0], cb, 2, cx->cur);
+                cx->end();
+                if (!ok) return fail(NTT_ERR_INTERNAL, "no u64-input column kernel for this plan");
+            } else {
+                return fail(NTT_ERR_INTERNAL, "u64 operands need the Montgomery kernels");
+            }
+        } else
         col_pass<MM>(pl, 0, false, !neg, ca, cbp, w0, w1, n, L, n, L, pl->tw_fwd[0], false, {}, false, cb, 2,
                      neg ? pl->twist_fwd : nullptr);
         for (int j = 1; j < m; ++j)

@@ -56,6 +56,9 @@ struct WorkArea {
     // true: stop in front of the outermost inverse column pass -- w0 then holds, per product, the input of that pass
     // (the CRT path runs it for four primes at once, fused with the merge: kernels_crt.hip); `ab` is not written
     bool stop_before_outer_inverse = false;
+    // non-null: a and b of the multiply are the caller's u64 operands and the first forward column pass reduces them
+    // modulo the plan's prime as it loads (Shoup constants of 1 and 2^32 mod p); needs a 32- or 64-point register level
+    const CrtPrime *u64_in = nullptr;
 };
 // device-pointer entry used by the CRT path (caller holds ctx->mu); area == nullptr: the plan's buffers and lanes
 int multiply_device_any(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,

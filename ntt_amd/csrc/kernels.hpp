@@ -37,6 +37,10 @@ struct ColArgs {
     // negacyclic products (x^n + 1): [L] table psi^(+-i); a forward pass multiplies its inputs by it,
     // the final inverse pass its outputs.  nullptr for the ordinary (cyclic) transform.
     const typename MM::tw_t *twist;
+    // first forward level of a residue product of the CRT path (col_kernel<..., U64IN>): `in` holds the caller's u64
+    // coefficients, reduced modulo this plan's prime as they are loaded (hi * 2^32 + lo with these two Shoup constants:
+    // 1 and 2^32 mod p) -- the implicit reduction of CRT_parallel's toMontgomery, main-openmp.cc:426-427
+    Barrett32::tw_t in_one, in_two32;
 };
 
 template <class MM>
@@ -103,6 +107,9 @@ void note_unsupported_launch(const char *what, int value);
 void launch_col(int kind, bool lazy, int logN1, bool inverse, bool half_in, const void *args,
                 const ModParams &mp, unsigned cols_per_row, unsigned batch, unsigned nops,
                 hipStream_t s);
+// the zero-padded first forward level reading u64 operands (Montgomery kernels, 32 or 64 points): false if no such kernel
+bool launch_col_u64in(bool lazy, int logN1, const void *args, const ModParams &mp, unsigned cols_per_row, unsigned batch,
+                      unsigned nops, hipStream_t s);
 void launch_col16(int kind, bool lazy, int logN1, bool inverse, bool half_in, const void *args,
                   const ModParams &mp, unsigned cols_per_row, unsigned batch, unsigned nops,
                   hipStream_t s);

@@ -16,7 +16,7 @@
 
 namespace ntt {
 
-template <class MM, bool LAZY, int LOGN1, bool INVERSE, bool HALF>
+template <class MM, bool LAZY, int LOGN1, bool INVERSE, bool HALF, bool U64IN = false>
 __global__ void __launch_bounds__(256) col_kernel(const ColArgs<MM> a, const ModParams m)
 {
     using O = Ops<MM, LAZY>;
@@ -39,8 +39,15 @@ __global__ void __launch_bounds__(256) col_kernel(const ColArgs<MM> a, const Mod
 #pragma unroll
     for (int i1 = 0; i1 < N1; ++i1) {
         if (HALF && i1 >= N1 / 2) x[i1] = 0;
-        else x[i1] = (!INVERSE && HALF) ? buf_load_nt(rin, voff + ((uint32_t)i1 << rowsh), 0)     // the caller's operand
-                                        : buf_load(rin, voff + ((uint32_t)i1 << rowsh), 0);
+        else if constexpr (U64IN) {
+            // the caller's u64 coefficient (beyond in_len: 0), reduced modulo p on the way in: hi * 2^32 + lo
+            const bufrsrc_t rin64 = make_buf(reinterpret_cast<const uint64_t *>(a.in[op]) + (size_t)blockIdx.y * a.in_stride, a.in_len * 8u);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rin64, (int)(2u * (voff + ((uint32_t)i1 << rowsh))), 0, NTT_NT_AUX);
+            const uint32_t h = csub(Barrett32::mul_tw(v[1], a.in_two32, m), m.p);
+            const uint32_t l = csub(Barrett32::mul_tw(v[0], a.in_one, m), m.p);
+            x[i1] = csub(h + l, m.p);
+        } else x[i1] = (!INVERSE && HALF) ? buf_load_nt(rin, voff + ((uint32_t)i1 << rowsh), 0)     // the caller's operand
+                                          : buf_load(rin, voff + ((uint32_t)i1 << rowsh), 0);
     }
     if (!INVERSE && a.twist) {                                    // negacyclic: x[i] * psi^i  (uniform branch)
         const bufrsrc_t rtwist = make_buf(a.twist, (uint32_t)sizeof(tw_t) << a.logM);
@@ -108,6 +115,19 @@ static void launch_col_l(int logN1, bool inverse, bool half_in, const ColArgs<MM
     case 6: launch_col_t<MM, LAZY, 6>(inverse, half_in, a, mp, grid, s); break;
     default: note_unsupported_launch("col_kernel: no instantiation for log2(N1) =", logN1); break;
     }
+}
+
+bool launch_col_u64in(bool lazy, int logN1, const void *args, const ModParams &mp, unsigned cols_per_row, unsigned batch,
+                      unsigned nops, hipStream_t s)
+{
+    const dim3 grid(cols_per_row / 256, batch, nops);
+    const auto &a = *static_cast<const ColArgs<Mont32> *>(args);
+    if (logN1 == 6 && lazy) hipLaunchKernelGGL((col_kernel<Mont32, true, 6, false, true, true>), grid, dim3(256), 0, s, a, mp);
+    else if (logN1 == 6) hipLaunchKernelGGL((col_kernel<Mont32, false, 6, false, true, true>), grid, dim3(256), 0, s, a, mp);
+    else if (logN1 == 5 && lazy) hipLaunchKernelGGL((col_kernel<Mont32, true, 5, false, true, true>), grid, dim3(256), 0, s, a, mp);
+    else if (logN1 == 5) hipLaunchKernelGGL((col_kernel<Mont32, false, 5, false, true, true>), grid, dim3(256), 0, s, a, mp);
+    else return false;
+    return true;
 }
 
 void launch_col(int kind, bool lazy, int logN1, bool inverse, bool half_in, const void *args,

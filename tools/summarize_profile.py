@@ -26,7 +26,7 @@ def short(name):
             tag = ""
             if k in ("col_kernel", "col16_kernel"):
                 # template args <MM, LAZY, LOGN1, INVERSE, HALF>
-                m = re.search(r"col(?:16)?_kernel<[^,]+, *(\w+), *(\d+), *(\w+), *(\w+)>", name)
+                m = re.search(r"col(?:16)?_kernel<[^,]+, *(\w+), *(\d+), *(\w+), *(\w+)[,>]", name)
                 tag = "_inv" if m and m.group(3) == "true" else "_fwd"
             return k + tag
     return None

@@ -36,7 +36,7 @@ FULL_RATE = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", 
 
 # (listing, substring of the mangled kernel name, SQ key in the profile summary, waves per product)
 KERNELS = {
-    "col_fwd": ("kernels_col.hip", "col_kernelINS_6Mont32ELb1ELi6ELb0ELb1E", "col_kernel_fwd", 2 * 4096 / 64),
+    "col_fwd": ("kernels_col.hip", "col_kernelINS_6Mont32ELb1ELi6ELb0ELb1ELb0E", "col_kernel_fwd", 2 * 4096 / 64),
     "row_mul": ("kernels_row.hip", "row_mul_kernelINS_6Mont32ELb1E", "row_mul_kernel", 64 * 256 / 64),
     "col_inv": ("kernels_col16.hip", "col16_kernelINS_6Mont32ELb1ELi2ELb1ELb0E", "col16_kernel_inv", 4096 * 4 / 64),
 }
