@@ -7,6 +7,8 @@
 //   NTT_ABL_NODATA  row kernels take synthetic inputs instead of global loads and skip the store
 //   NTT_ABL_NOTW    4-step/row twiddles come from the SGPR root table instead of global loads
 //   NTT_ABL_NOLDS   the LDS exchanges (and their barriers) are skipped
+//   NTT_ABL_VEC4    16-byte global accesses from the wrong positions (what a permuted hand-off layout would allow):
+//                   +0.5 % end to end (round 2), so the dword accesses are not what the row kernel waits for
 #if defined(NTT_ABL_NOTW)
 #define NTT_TW(tab, idx) a.roots.w[(idx) & 31]
 #else
@@ -107,6 +109,14 @@ __device__ __forceinline__ void row_mul_body(const RowArgs<MM> &a, const ModPara
 #pragma unroll
     for (int j = 0; j < 16; ++j) { xa[j] = t + j; xb[j] = t * 3 + j; }
     (void)pa; (void)pb;
+#elif defined(NTT_ABL_VEC4)
+    // timing experiment only (results are wrong): 16-byte accesses, as a permuted hand-off layout would allow
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 va = reinterpret_cast<const uint4 *>(pa + 1024 * q)[t], vb = reinterpret_cast<const uint4 *>(pb + 1024 * q)[t];
+        xa[4 * q] = va.x; xa[4 * q + 1] = va.y; xa[4 * q + 2] = va.z; xa[4 * q + 3] = va.w;
+        xb[4 * q] = vb.x; xb[4 * q + 1] = vb.y; xb[4 * q + 2] = vb.z; xb[4 * q + 3] = vb.w;
+    }
 #else
 #pragma unroll
     for (int j = 0; j < 16; ++j) xa[j] = pa[t + 256 * j];
@@ -124,6 +134,10 @@ __device__ __forceinline__ void row_mul_body(const RowArgs<MM> &a, const ModPara
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc ^= xa[j];
     if (acc == 0x9e3779b9u) po[t] = acc;            // keeps the computation live, practically never stores
+#elif defined(NTT_ABL_VEC4)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        reinterpret_cast<uint4 *>(po + 1024 * q)[t] = make_uint4(xa[4 * q], xa[4 * q + 1], xa[4 * q + 2], xa[4 * q + 3]);
 #else
 #pragma unroll
     for (int j = 0; j < 16; ++j) po[t + 256 * j] = xa[j];
