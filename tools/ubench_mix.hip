@@ -76,7 +76,7 @@ static void run(const char *name, double insts_per_iter)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int w = 0; w < 40; ++w) k<MODE><<<blocks, 256>>>(out, clk, c, iters);   // ~1-2 s of load before the timed launches
+    for (int w = 0; w < 300; ++w) k<MODE><<<blocks, 256>>>(out, clk, c, iters);   // ~3 s of load before the timed launches (the power controller settles in ~0.5 s)
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
     const int reps = 10;
