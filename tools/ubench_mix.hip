@@ -64,23 +64,85 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint64_t *clk, P c, int 
     if (threadIdx.x == 0 && blockIdx.x < 64) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
-template <int MODE>
-static void run(const char *name, double insts_per_iter)
+
+// The same butterflies with the instruction ORDER pinned by hand: per stage, GROUP butterflies at a time go through
+// add / sub / borrow-subtract+select / multiply-add / multiply / multiply-add as runs of GROUP equal instructions
+// (GROUP = 1 is the order the compiler picks above: one butterfly after the other, every instruction depending on
+// the one before it).
+template <int GROUP>
+__global__ void __launch_bounds__(256) kg(uint32_t *out, uint64_t *clk, P c, int iters)
+{
+    uint32_t x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = threadIdx.x * 2654435761u + i * 40503u + blockIdx.x;
+    const uint64_t C = (uint64_t)c.p2 * c.w;
+    uint32_t tw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tw[j] = c.w + (uint32_t)j;
+    const uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int half = 8 >> s;
+#pragma unroll
+            for (int g = 0; g < 8; g += GROUP) {
+                uint32_t sum[GROUP], d[GROUP], q[GROUP];
+                uint64_t T[GROUP];
+                int lo[GROUP], hi[GROUP];
+#pragma unroll
+                for (int e = 0; e < GROUP; ++e) {
+                    const int bf = g + e;                            // butterfly bf of this stage
+                    lo[e] = (bf / half) * 2 * half + bf % half;
+                    hi[e] = lo[e] + half;
+                }
+#pragma unroll
+                for (int e = 0; e < GROUP; ++e) asm volatile("v_add_u32 %0, %1, %2" : "=v"(sum[e]) : "v"(x[lo[e]]), "v"(x[hi[e]]));
+#pragma unroll
+                for (int e = 0; e < GROUP; ++e) asm volatile("v_sub_u32 %0, %1, %2" : "=v"(d[e]) : "v"(x[lo[e]]), "v"(x[hi[e]]));
+#pragma unroll
+                for (int e = 0; e < GROUP; ++e) {
+                    uint32_t t;
+                    asm volatile("v_subrev_co_u32 %0, vcc, %2, %3\n\tv_cndmask_b32 %1, %0, %3, vcc"
+                                 : "=&v"(t), "=v"(x[lo[e]]) : "s"(c.p2), "v"(sum[e]) : "vcc");
+                }
+#pragma unroll
+                for (int e = 0; e < GROUP; ++e) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(T[e]) : "v"(d[e]), "v"(tw[(g + e) & 7]), "s"(C) : "vcc");
+#pragma unroll
+                for (int e = 0; e < GROUP; ++e) asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(q[e]) : "v"((uint32_t)T[e]), "s"(c.nprime));
+#pragma unroll
+                for (int e = 0; e < GROUP; ++e) {
+                    uint64_t t2;
+                    asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(t2) : "v"(q[e]), "s"(c.p), "v"(T[e]) : "vcc");
+                    x[hi[e]] = (uint32_t)(t2 >> 32);
+                }
+            }
+        }
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc ^= x[i];
+    if (acc == 0x12345u) out[0] = acc;
+    if (threadIdx.x == 0 && blockIdx.x < 64) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+template <typename K>
+static void run_kernel(K kern, const char *name, double insts_per_iter, int warm = 300, int wg_per_cu = 7)
 {
     uint32_t *out;
     uint64_t *clk, h[128];
     CK(hipMalloc(&out, 64));
     CK(hipMalloc(&clk, sizeof(h)));
     const P c{998244353u, 2 * 998244353u, 998244351u, 299560064u};
-    const int blocks = 256 * 7, iters = 4000;                       // 7 workgroups of 4 waves per CU, as the row kernel
+    const int blocks = 256 * wg_per_cu, iters = 4000 * 7 / wg_per_cu;                       // 7 workgroups of 4 waves per CU, as the row kernel
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int w = 0; w < 300; ++w) k<MODE><<<blocks, 256>>>(out, clk, c, iters);   // ~3 s of load before the timed launches (the power controller settles in ~0.5 s)
+    for (int w = 0; w < warm; ++w) kern<<<blocks, 256>>>(out, clk, c, iters);   // ~3 s of load before the timed launches (the power controller settles in ~0.5 s)
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
     const int reps = 10;
-    for (int r = 0; r < reps; ++r) k<MODE><<<blocks, 256>>>(out, clk, c, iters);
+    for (int r = 0; r < reps; ++r) kern<<<blocks, 256>>>(out, clk, c, iters);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -92,9 +154,12 @@ static void run(const char *name, double insts_per_iter)
     const double wave_insts = (double)reps * blocks * 4 * iters * insts_per_iter;        // 4 waves per block
     const double lane_ops = wave_insts * 64;
     const double sec = ms * 1e-3;
-    printf("%-7s %6.1f T lane-op/s  %5.2f cycles per wave-instr per SIMD at 2.4 GHz  %5.2f at the in-kernel clock %.2f GHz\n", name,
+    printf("%-10s %6.1f T lane-op/s  %5.2f cycles per wave-instr per SIMD at 2.4 GHz  %5.2f at the in-kernel clock %.2f GHz\n", name,
            lane_ops / sec / 1e12, sec * 2.4e9 * 1024 / wave_insts, sec * ghz * 1e9 * 1024 / wave_insts, ghz);
 }
+
+template <int MODE>
+static void run(const char *name, double insts_per_iter) { run_kernel(k<MODE>, name, insts_per_iter); }
 
 int main()
 {
@@ -104,5 +169,15 @@ int main()
     run<2>("addsub", 32 * 4.0);   // add, subrev_co, cndmask, sub
     run<0>("mix", 32 * 7.0);
     run<3>("mix-vcc", 32 * 7.0);  // the same with the multiply-add's unused carry-out sent to vcc instead of an SGPR pair
+    run_kernel(kg<1>, "order-1", 32 * 7.0, 100);   // hand-pinned order, runs of 1 / 2 / 4 / 8 equal instructions
+    run_kernel(kg<2>, "order-2", 32 * 7.0, 100);
+    run_kernel(kg<4>, "order-4", 32 * 7.0, 100);
+    run_kernel(kg<8>, "order-8", 32 * 7.0, 100);
+    // one and two waves per SIMD: does a run of equal instructions inside ONE wave issue faster than the interleaved order?
+    run_kernel(kg<1>, "o1 1w/SIMD", 32 * 7.0, 30, 1);
+    run_kernel(kg<8>, "o8 1w/SIMD", 32 * 7.0, 30, 1);
+    run_kernel(kg<1>, "o1 2w/SIMD", 32 * 7.0, 30, 2);
+    run_kernel(kg<8>, "o8 2w/SIMD", 32 * 7.0, 30, 2);
+    run_kernel(kg<8>, "o8 4w/SIMD", 32 * 7.0, 30, 4);
     return 0;
 }
