@@ -247,6 +247,24 @@ static int build_tables(ntt_plan *pl)
             }
         }
     }
+    if (pl->fused) {
+        // seq_product_kernel: row k1 of the forward column level as a dot product over the column's nonzero inputs
+        // i = i1 * 4096 + i2 with (psi * w_L^k1)^i -- N1-point root, 4-step twiddle and negacyclic twist in one entry
+        const uint32_t N1 = 1u << pl->level_log[0], cols = (pl->negacyclic ? N1 : N1 / 2) * (uint32_t)kRowLen;
+        const uint32_t psi = pl->negacyclic ? h_powmod(pl->g, (p - 1) / (2 * L), p) : 1u;
+        std::vector<typename MM::tw_t> t((size_t)N1 * cols);
+        uint32_t base = psi;
+        for (uint32_t k1 = 0; k1 < N1; ++k1) {
+            uint32_t cur = 1;
+            for (uint32_t i = 0; i < cols; ++i) {
+                t[(size_t)k1 * cols + i] = MM::make_tw(cur, mp);
+                cur = h_mulmod(cur, base, p);
+            }
+            base = h_mulmod(base, wL, p);
+        }
+        int rc = upload_table<MM>(pl, t, &pl->seq_tw);
+        if (rc) return rc;
+    }
     // row tables
     const uint32_t w4096 = h_powmod(wL, L / kRowLen, p), iw4096 = h_powmod(iwL, L / kRowLen, p);
     const uint32_t w256 = h_powmod(w4096, 16, p), iw256 = h_powmod(iw4096, 16, p);
@@ -402,21 +420,18 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
         small_pass<MM>(pl, 0, a, b, ab, n, ab_stride, n, out_len, (unsigned)batch);
         return NTT_OK;
     }
-    if (pl->fused) {                                       // linear, L = 8192: column level and rows in one kernel
-        FusedArgs<MM> fa{};
-        fa.r.row = fill_row<MM>(pl, a, b, ab);
-        fa.r.in_stride = n; fa.r.out_stride = ab_stride;
-        fa.r.in_len = n; fa.r.out_len = out_len;
-        std::memcpy(&fa.r.scale, pl->scale_mul.data(), sizeof(fa.r.scale));
-        if (neg) {
-            fa.r.twist = static_cast<const typename MM::tw_t *>(pl->twist_fwd);
-            fa.r.itwist = static_cast<const typename MM::tw_t *>(pl->twist_inv);
-        }
-        fa.tw_fwd = static_cast<const typename MM::tw_t *>(pl->tw_fwd[0]);
-        fa.tw_inv = static_cast<const typename MM::tw_t *>(pl->tw_inv[0]);
+    if (pl->fused) {                                       // L = 8192 / 16384: one kernel, rows one after the other
+        SeqArgs<MM> sa{};
+        sa.r.row = fill_row<MM>(pl, a, b, ab);
+        sa.r.in_stride = n; sa.r.out_stride = ab_stride;
+        sa.r.in_len = n; sa.r.out_len = out_len;
+        if (neg) sa.r.itwist = static_cast<const typename MM::tw_t *>(pl->twist_inv);
+        sa.tw_in = static_cast<const typename MM::tw_t *>(pl->seq_tw);
+        sa.tw_inv = static_cast<const typename MM::tw_t *>(pl->tw_inv[0]);
+        sa.plain_row0 = neg ? 0 : 1;
         ntt_ctx *cx = pl->ctx;
         cx->begin(K_ROW_MUL);
-        launch_fused_product(pl->kind, pl->lazy, &fa, pl->mp, (unsigned)batch, cx->cur);
+        launch_seq_product(pl->kind, pl->lazy, pl->level_log[0], !neg, &sa, pl->mp, (unsigned)batch, cx->cur);
         cx->end();
         return NTT_OK;
     }
@@ -923,11 +938,14 @@ static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_ki
             logM -= pl->level_log[j];
         }
         pl->nlevels = m;
-        // linear products of L = 8192: one kernel does the column level in registers around the rows (kernels_fused.hip)
-        // (0.077 -> 0.043 us per product, tools/sweep_small.py; NTT_AMD_FUSED=0 keeps the three kernels)
-        bool fused_ok = true;
-        if (const char *e = std::getenv("NTT_AMD_FUSED")) fused_ok = e[0] != '0';
-        pl->fused = fused_ok && m == 1 && pl->level_log[0] == 1 && !negacyclic;
+        // L = 8192 and the linear L = 16384: one kernel does the column level around the rows, which it takes one after
+        // the other (kernels_fused.hip; 0.077 -> 0.044, 0.137 -> 0.113, negacyclic 8192 0.083 -> 0.054 us per product,
+        // profiles/time_medium_r02.txt).  The full-length L = 16384 only ties and stays on the three kernels, which
+        // NTT_AMD_FUSED=0 keeps everywhere
+        // (=2 sends the full-length L = 16384 through the one kernel as well)
+        int fused_mode = 1;
+        if (const char *e = std::getenv("NTT_AMD_FUSED")) fused_mode = std::atoi(e);
+        pl->fused = fused_mode && m == 1 && (pl->level_log[0] == 1 || (pl->level_log[0] == 2 && (!negacyclic || fused_mode == 2)));
         // work buffers: two operands per product, `chunk` products per launch and per lane.
         // Measured (profiles/sweep_chunk_r01.txt, profiles/sweep_chunk_r01d.txt): throughput rises
         // with the chunk up to ~40 products (fewer launches, smaller tail rounds), is flat from 40

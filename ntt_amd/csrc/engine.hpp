@@ -134,7 +134,8 @@ struct ntt_plan {
     // multiply goes through this companion plan of L = 4096; transforms keep the plan's own length
     ntt_plan *wide = nullptr;
     bool fold2048 = false;                // companion of a negacyclic n = 2048 plan: linear product of L = 4096, folded at the store
-    bool fused = false;                   // L = 8192 / 16384 products run in fused_product_kernel
+    bool fused = false;                   // L = 8192 / 16384: the product runs in one kernel (seq_product_kernel, kernels_fused.hip)
+    void *seq_tw = nullptr;               // its forward table [N1][NIN * 4096]: (psi w_L^k1)^i
     void *twist_fwd = nullptr, *twist_inv = nullptr, *small_itwist = nullptr;
     // by-value kernel constants, raw bytes of Roots64<MM> / tw_t
     std::vector<unsigned char> roots, iroots, scale_mul, scale_plain;

@@ -64,12 +64,18 @@ struct Row4096Args {
     int fold;                            // 1: store c[i] = ab[i] - ab[i + 2048], i < 2048 (x^2048 + 1 from the linear product)
 };
 
-// A whole linear product of L = 8192 in one kernel (kernels_fused.hip): Row4096Args plus the level-0 column
-// tables [N1][4096]; r.itwist here is the plain psi^-i table (the scale sits in `r.scale` and `tw_inv`).
+// A whole product of L = 8192 or 16384 in one kernel, rows one after the other (kernels_fused.hip, seq_product_kernel):
+// Row4096Args (r.twist unused: the negacyclic twist is part of tw_in; r.itwist is the plain psi^-i table; r.scale unused:
+// the scale sits in tw_inv) plus the two column-level tables.
 template <class MM>
-struct FusedArgs {
+struct SeqArgs {
     Row4096Args<MM> r;
-    const typename MM::tw_t *tw_fwd, *tw_inv;
+    // [N1][NIN * 4096], entry (k1, i) = (psi * w_L^k1)^i (psi = 1 for the cyclic transform): row k1 of the forward
+    // column level, 4-step twiddle and negacyclic twist included, is the dot product of the NIN inputs
+    // i = i1 * 4096 + i2 with these; NIN = N1 / 2 for zero-padded (linear) operands, N1 otherwise
+    const typename MM::tw_t *tw_in;
+    const typename MM::tw_t *tw_inv;     // [N1][4096]: level-0 inverse twiddles, scale folded in (row 0 = the scale)
+    int plain_row0;                      // 1: row 0 of tw_in is all ones (cyclic transform): the inputs are added up
 };
 
 template <class MM>
@@ -244,8 +250,9 @@ struct Row64ProdArgs {
     int fold;                            // 1: store c[i] = ab[i] - ab[i + 2048], i < 2048
 };
 void launch_row64_product(const Row64ProdArgs &a, const ModParams64 &mp, unsigned batch, hipStream_t s);
-void launch_fused_product(int kind, bool lazy, const void *args, const ModParams &mp,
-                          unsigned batch, hipStream_t s);
+// logN1 in {1, 2}; half: the operands' upper half is zero padding (linear product)
+void launch_seq_product(int kind, bool lazy, int logN1, bool half, const void *args, const ModParams &mp,
+                        unsigned batch, hipStream_t s);
 void launch_row64_mul(const Row64Args &a, const ModParams64 &mp, unsigned rows, hipStream_t s);
 void launch_col64(int logN1, bool inverse, bool half_in, const Col64Args &a, const ModParams64 &mp,
                   unsigned cols_per_row, unsigned batch, unsigned nops, hipStream_t s);

@@ -73,7 +73,7 @@ def test_negacyclic_tiny_schoolbook(nt, ctx, p):
 
 
 # L = n: small path (<= 4096), one column level of 2 / 16 / 32 / 64 points, two levels (2^19)
-@pytest.mark.parametrize("n", [256, 1024, 2048, 4096, 8192, 65536, 131072, 262144, 524288])
+@pytest.mark.parametrize("n", [256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288])
 @pytest.mark.parametrize("p,kind", [(P, 0), (P_STRICT, 0), (P_C, 1)])
 def test_negacyclic_vs_linear_oracle(nt, ctx, n, p, kind):
     rng = np.random.default_rng(n + p % 1000)
@@ -84,6 +84,26 @@ def test_negacyclic_vs_linear_oracle(nt, ctx, n, p, kind):
     got = plan.multiply(a, b)[0]
     plan.close()
     assert np.array_equal(got, negacyclic_from_linear(a, b, p))
+
+
+@pytest.mark.parametrize("seq_mode", ["1", "2", "0"])
+def test_negacyclic_one_kernel_batched(nt, ctx, seq_mode, monkeypatch):
+    """Full-length L = 8192 (default) and 16384 (NTT_AMD_FUSED=2 only: it ties with the three kernels) in
+    seq_product_kernel (kernels_fused.hip): batches, a row stride beyond n, both reductions, lazy and strict primes;
+    NTT_AMD_FUSED=0 is the three-kernel path on the same inputs."""
+    monkeypatch.setenv("NTT_AMD_FUSED", seq_mode)
+    rng = np.random.default_rng(31)
+    for n in (8192, 16384):
+        for p, kind in ((P, nt.MONTGOMERY), (P_STRICT, nt.MONTGOMERY), (P_C, nt.BARRETT), (P_STRICT, nt.BARRETT)):
+            B = 5
+            a, b = rand(rng, (B, n), p), rand(rng, (B, n), p)
+            a[0, -1] = b[0, -1] = p - 1
+            plan = ctx.negacyclic_plan(p, n, B, kind)
+            got = plan.multiply(a, b, out=np.full((B, n + 3), 0xC3C3C3C3, dtype=np.uint32), out_stride=n + 3)
+            plan.close()
+            for r in range(B):
+                assert np.array_equal(got[r, :n], negacyclic_from_linear(a[r], b[r], p)), (n, p, kind, r)
+            assert np.all(got[:, n:] == 0xC3C3C3C3)
 
 
 def test_negacyclic_ring_identities(ctx):

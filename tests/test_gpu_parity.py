@@ -146,6 +146,27 @@ def test_randomised_shapes_and_primes(ctx):
         plan.close()
 
 
+@pytest.mark.parametrize("seq_mode", ["1", "0"])
+def test_one_kernel_medium_products(ctx, seq_mode, monkeypatch):
+    """L = 8192 and 16384: whole products in one kernel with the rows one after the other (seq_product_kernel,
+    kernels_fused.hip; NTT_AMD_FUSED=0 keeps the three kernels on the same inputs) -- ragged n
+    on both sides of every boundary, batches, odd strides, both reductions, lazy / strict / small primes."""
+    monkeypatch.setenv("NTT_AMD_FUSED", seq_mode)
+    rng = np.random.default_rng(77)
+    for n in (2049, 3000, 4096, 4097, 5000, 6143, 8191, 8192):
+        for p, kind in ((998244353, 0), (469762049, 1), (1224736769, 0), (1224736769, 1), (7340033, 0)):
+            B = 3
+            stride = 2 * n - 1 + (n % 3)
+            a, b = rand_poly(rng, n, p, B), rand_poly(rng, n, p, B)
+            a[0, 0] = a[1, -1] = b[1, -1] = p - 1
+            plan = ctx.plan(p, n, B, kind)
+            got = plan.multiply(a, b, out=np.full((B, stride), 0x5A5A5A5A, dtype=np.uint32), out_stride=stride)
+            plan.close()
+            for r in range(B):
+                assert np.array_equal(got[r, :2 * n - 1], orc.poly_multiply(a[r], b[r], p, kind="barrett")), (n, p, kind, r)
+            assert np.all(got[:, 2 * n - 1:] == 0x5A5A5A5A), (n, p, kind)
+
+
 def test_multi_level_columns(ctx):
     # L = 2^19 and 2^20: two column levels in front of the 4096-point rows
     rng = np.random.default_rng(5)

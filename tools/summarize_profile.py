@@ -72,15 +72,28 @@ def main():
                   "--no-cpu-baseline --steps 5 --warmup 2` (durations) and separate `--pmc` passes "
                   "(`--steps 1 --warmup 1`), see tools/profile.sh.  Per-launch averages.\n\n")
         out.write("| kernel | launches | avg us | total ms | read MiB raw / x2 | write MiB | VALU insts/wave | "
-                  "LDS bank-conflict cyc / LDS active | TCC hit rate |\n|---|---|---|---|---|---|---|---|---|\n")
+                  "LDS bank-conflict cyc / LDS active | TCC hit rate | VALU instr per SIMD-cycle | wait_inst_any / wave_cycles | "
+                  "VMEM instr/wave rd + wr |\n|---|---|---|---|---|---|---|---|---|---|---|---|\n")
         for k, s in summary.items():
             rd = f"{s.get('hbm_read_bytes_raw', 0) / 2**20:.2f} / {s.get('hbm_read_bytes_x2', 0) / 2**20:.2f}"
             wr = f"{s.get('hbm_write_bytes', 0) / 2**20:.2f}"
             valu = s.get("SQ_INSTS_VALU", 0) / max(s.get("SQ_WAVES", 1), 1)
             lds = f"{s.get('SQ_LDS_BANK_CONFLICT', 0):.0f} / {s.get('SQ_ACTIVE_INST_LDS', 0):.0f}"
             hit = s.get("TCC_HIT_sum", 0) / max(s.get("TCC_HIT_sum", 0) + s.get("TCC_MISS_sum", 0), 1)
+            # SQ_BUSY_CYCLES is summed over the 32 shader engines, each 8 CUs x 4 SIMDs; SQ_ACTIVE_INST_VALU reads
+            # identical to SQ_INSTS_VALU on this stack (an instruction count, not cycles), so the utilisation
+            # figure is instructions per SIMD and busy cycle (the butterfly mix peaks at 1 / 3.8 = 0.263)
+            per_simd = s.get("SQ_INSTS_VALU", 0) / max(s.get("SQ_BUSY_CYCLES", 1), 1) / 32
+            s["valu_insts_per_simd_cycle"] = per_simd
+            wait = s.get("SQ_WAIT_INST_ANY", 0) / max(s.get("SQ_WAVE_CYCLES", 1), 1)
+            vm = (f"{s.get('SQ_INSTS_VMEM_RD', 0) / max(s.get('SQ_WAVES', 1), 1):.0f} + "
+                  f"{s.get('SQ_INSTS_VMEM_WR', 0) / max(s.get('SQ_WAVES', 1), 1):.0f}")
             out.write(f"| {k} | {s['launches']} | {s['avg_us']:.1f} | {s['total_ms']:.2f} | {rd} | {wr} | "
-                      f"{valu:.0f} | {lds} | {hit:.2f} |\n")
+                      f"{valu:.0f} | {lds} | {hit:.2f} | {per_simd:.3f} | {wait:.2f} | {vm} |\n")
+        out.write("\nVALU instr per SIMD-cycle = SQ_INSTS_VALU / SQ_BUSY_CYCLES / 32 (SQ_BUSY_CYCLES is summed over the 32 shader "
+                  "engines of 8 CUs x 4 SIMDs; SQ_ACTIVE_INST_VALU reads identical to SQ_INSTS_VALU on this stack, so it is not a "
+                  "cycle count).  The butterfly mix peaks at 1 / 3.8 = 0.263 (profiles/ubench_mix_r02.txt); the counter passes run "
+                  "with the profiler serialising the kernels, i.e. every kernel alone on the chip.\n")
     print(open(os.path.join(dst, f"{tag}_summary.md")).read())
     # profiles/traffic.json feeds bench.py's roofline.traffic: PMC bytes per product and kernel of THIS build
     # (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md "HBM"), stamped with the sha256 of the kernel sources
