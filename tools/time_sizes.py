@@ -16,7 +16,11 @@ os.environ["NTT_AMD_STREAMS"] = "1"
 ctx = ntt_amd.Context(0)
 p = 469762049
 rng = np.random.default_rng(0)
-for name, lgn in (("linear", 13), ("negacyclic", 13), ("linear", 14), ("negacyclic", 14), ("linear", 15), ("linear", 16)):
+CASES = (("linear", 13), ("negacyclic", 13), ("linear", 14), ("negacyclic", 14), ("linear", 15), ("negacyclic", 15), ("linear", 16),
+         ("negacyclic", 16), ("negacyclic", 17), ("linear", 17))
+if len(sys.argv) > 1:
+    CASES = tuple((a.split(":")[0], int(a.split(":")[1])) for a in sys.argv[1:])
+for name, lgn in CASES:
     n = 1 << lgn
     B = (1 << 25) // n
     a = torch.from_numpy(rng.integers(0, p, size=(B, n), dtype=np.int64).astype(np.int32)).cuda()
