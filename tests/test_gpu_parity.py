@@ -167,6 +167,43 @@ def test_one_kernel_medium_products(ctx, seq_mode, monkeypatch):
             assert np.all(got[:, 2 * n - 1:] == 0x5A5A5A5A), (n, p, kind)
 
 
+def test_one_kernel_vs_three_kernels_random(ctx, monkeypatch):
+    """Seeded sweep, n in (2048, 8192], linear and negacyclic: the one-kernel product (default) against the
+    three-kernel path (NTT_AMD_FUSED=0) bit for bit on every row, and one row per trial against the oracle."""
+    rng = np.random.default_rng(424242)
+    primes = [998244353, 469762049, 1224736769, 7340033, 2013265921, 167772161]
+    for trial in range(40):
+        p = int(primes[rng.integers(len(primes))])
+        neg = bool(rng.integers(2))
+        n = int(1 << rng.integers(13, 15)) if neg else int(rng.integers(2049, 8193))
+        if neg and n == 16384:
+            monkeypatch.setenv("NTT_AMD_FUSED", "2")      # the full-length L = 16384 is not the default route
+        else:
+            monkeypatch.delenv("NTT_AMD_FUSED", raising=False)
+        B = int(rng.integers(1, 6))
+        kind = int(rng.integers(2))
+        cols = n if neg else 2 * n - 1
+        stride = cols + int(rng.integers(0, 4))
+        a, b = rand_poly(rng, n, p, B), rand_poly(rng, n, p, B)
+        mk = (lambda: ctx.negacyclic_plan(p, n, B, kind)) if neg else (lambda: ctx.plan(p, n, B, kind))
+        plan = mk()
+        one = plan.multiply(a, b, out=np.full((B, stride), 0x11111111, dtype=np.uint32), out_stride=stride)
+        plan.close()
+        monkeypatch.setenv("NTT_AMD_FUSED", "0")
+        plan = mk()
+        three = plan.multiply(a, b, out=np.full((B, stride), 0x11111111, dtype=np.uint32), out_stride=stride)
+        plan.close()
+        assert np.array_equal(one, three), (trial, p, n, neg, B, kind)
+        if p != 2013265921:                               # (generator 31: the oracle's g = 3 transform is not valid there)
+            r = int(rng.integers(B))
+            ab = np.asarray(orc.poly_multiply(a[r], b[r], p, kind="barrett")).astype(np.int64)
+            if neg:
+                hi = np.zeros(n, dtype=np.int64)
+                hi[:n - 1] = ab[n:]
+                ab = (ab[:n] - hi) % p
+            assert np.array_equal(one[r, :cols], ab.astype(np.uint32)), (trial, p, n, neg, r)
+
+
 def test_multi_level_columns(ctx):
     # L = 2^19 and 2^20: two column levels in front of the 4096-point rows
     rng = np.random.default_rng(5)
