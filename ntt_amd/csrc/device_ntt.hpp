@@ -165,11 +165,8 @@ __device__ __forceinline__ void reg_ntt(uint32_t (&x)[1 << LOGN], const Roots64<
                     x[blk + j + half] = O::sub_raw(u, v, m);
                 } else {
                     x[blk + j] = O::add(u, v, m);
-                    // signed-mad form for <= 16 points (7 twiddle constants); the 32/64-point
-                    // register transforms would need 15/31 extra SGPR pairs and measured slower
                     if (j == 0) x[blk + j + half] = O::sub(u, v, m);
-                    else if (LOGN <= 4) x[blk + j + half] = O::mul_tw_diff(u, v, roots.w[j * step], m);
-                    else x[blk + j + half] = O::mul_tw(O::sub_raw(u, v, m), roots.w[j * step], m);
+                    else x[blk + j + half] = O::mul_tw_diff(u, v, roots.w[j * step], m);   // signed-mad form
                 }
             }
         }

@@ -166,14 +166,18 @@ struct Mont32 {
     {
         return redc_lazy((uint64_t)x * w, m);
     }
-    // (u - v + bound) * w mod p in [0, 2p) for u, v in [0, bound), bound <= 2^31: the "+ bound"
-    // rides in the 64-bit addend of a signed v_mad_i64_i32 (bound * w is wave-uniform), which
-    // saves the separate v_add_u32 of the sub_raw() form.
+    // (u - v) * w mod p in [0, 2p) for u, v in [0, bound), bound <= min(2p, 2^31): the signed difference goes
+    // straight into a signed v_mad_i64_i32 whose 64-bit addend p * 2^31 makes the sum non-negative (|u - v| * w <
+    // bound * p <= p * 2^31) without changing it modulo p, and keeps it below p * 2^32, so redc_lazy applies.  This
+    // saves the separate v_add_u32 of the sub_raw() form, and the addend is ONE wave-uniform constant for every
+    // twiddle (round 1 used bound * w: an SGPR pair per twiddle, which kept the 32- and 64-point register
+    // transforms on the longer form).
     static NTT_HD uint32_t mul_tw_diff(uint32_t u, uint32_t v, tw_t w, uint32_t bound, const ModParams &m)
     {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(NTT_NO_MADI64)
         // hipcc expands a signed 32x32+64 C++ expression into five instructions; ask for the one
-        const uint64_t C = (uint64_t)bound * w;         // wave-uniform: scalar multiply
+        (void)bound;
+        const uint64_t C = (uint64_t)m.p << 31;
         uint64_t T, carry;
         asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(T), "=s"(carry) : "v"(u - v), "v"(w), "s"(C));
         return redc_lazy(T, m);
