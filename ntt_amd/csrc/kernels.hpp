@@ -41,6 +41,9 @@ struct ColArgs {
     // coefficients, reduced modulo this plan's prime as they are loaded (hi * 2^32 + lo with these two Shoup constants:
     // 1 and 2^32 mod p) -- the implicit reduction of CRT_parallel's toMontgomery, main-openmp.cc:426-427
     Barrett32::tw_t in_one, in_two32;
+    // col_kernel only: > 0 = batch rows in total, a workgroup takes rows blockIdx.y, blockIdx.y + gridDim.y, ...
+    // (0: one row per workgroup); set by launch_col, see there
+    uint32_t loop_batch;
 };
 
 template <class MM>

@@ -12,12 +12,14 @@
 //          beyond in_len return 0; HALF skips the upper half entirely)
 // Inverse: row k1 times w_M^(-i2*k1) [row 0 times scale0] -> inverse NTT_N1 -> row i1; the
 //          outermost inverse pass stores canonical residues and drops indices >= out_len.
+#include <cstdlib>
 #include "device_ntt.hpp"
 
 namespace ntt {
 
-template <class MM, bool LAZY, int LOGN1, bool INVERSE, bool HALF, bool U64IN = false>
-__global__ void __launch_bounds__(256) col_kernel(const ColArgs<MM> a, const ModParams m)
+// one thread, one column of batch row `by`
+template <class MM, bool LAZY, int LOGN1, bool INVERSE, bool HALF, bool U64IN>
+__device__ __forceinline__ void col_body(const ColArgs<MM> &a, const ModParams &m, const uint32_t by)
 {
     using O = Ops<MM, LAZY>;
     using tw_t = typename MM::tw_t;
@@ -28,8 +30,8 @@ __global__ void __launch_bounds__(256) col_kernel(const ColArgs<MM> a, const Mod
     const uint32_t base = ((c >> a.logS) << a.logM) + i2;        // blk * M + i2
     const int op = blockIdx.z;
     // descriptors of this batch row: the range check gives zero padding (in_len) and the output cut
-    const bufrsrc_t rin = make_buf(a.in[op] + (size_t)blockIdx.y * a.in_stride, a.in_len * 4u);
-    const bufrsrc_t rout = make_buf(a.out[op] + (size_t)blockIdx.y * a.out_stride, a.out_len * 4u);
+    const bufrsrc_t rin = make_buf(a.in[op] + (size_t)by * a.in_stride, a.in_len * 4u);
+    const bufrsrc_t rout = make_buf(a.out[op] + (size_t)by * a.out_stride, a.out_len * 4u);
     const bufrsrc_t rtw = make_buf(a.tw, (uint32_t)sizeof(tw_t) << a.logM);
     const uint32_t voff = base * 4u;
     const uint32_t twoff = i2 * (uint32_t)sizeof(tw_t);
@@ -41,7 +43,7 @@ __global__ void __launch_bounds__(256) col_kernel(const ColArgs<MM> a, const Mod
         if (HALF && i1 >= N1 / 2) x[i1] = 0;
         else if constexpr (U64IN) {
             // the caller's u64 coefficient (beyond in_len: 0), reduced modulo p on the way in: hi * 2^32 + lo
-            const bufrsrc_t rin64 = make_buf(reinterpret_cast<const uint64_t *>(a.in[op]) + (size_t)blockIdx.y * a.in_stride, a.in_len * 8u);
+            const bufrsrc_t rin64 = make_buf(reinterpret_cast<const uint64_t *>(a.in[op]) + (size_t)by * a.in_stride, a.in_len * 8u);
             const auto v = __builtin_amdgcn_raw_buffer_load_b64(rin64, (int)(2u * (voff + ((uint32_t)i1 << rowsh))), 0, NTT_NT_AUX);
             const uint32_t h = csub(Barrett32::mul_tw(v[1], a.in_two32, m), m.p);
             const uint32_t l = csub(Barrett32::mul_tw(v[0], a.in_one, m), m.p);
@@ -90,6 +92,19 @@ __global__ void __launch_bounds__(256) col_kernel(const ColArgs<MM> a, const Mod
     }
 }
 
+// A launch covers the batch in grid.y; a WALKING launch (a.loop_batch > 0, see launch_col) has fewer workgroups than
+// batch rows and each takes rows blockIdx.y, blockIdx.y + gridDim.y, ...: what does not depend on the row -- the
+// column's 4-step twiddles above all -- is then loaded once per workgroup.
+template <class MM, bool LAZY, int LOGN1, bool INVERSE, bool HALF, bool U64IN = false>
+__global__ void __launch_bounds__(256) col_kernel(const ColArgs<MM> a, const ModParams m)
+{
+    uint32_t by = blockIdx.y;
+    do {
+        col_body<MM, LAZY, LOGN1, INVERSE, HALF, U64IN>(a, m, by);
+        by += gridDim.y;
+    } while (by < a.loop_batch);
+}
+
 template <class MM, bool LAZY, int LOGN1>
 static void launch_col_t(bool inverse, bool half_in, const ColArgs<MM> &a, const ModParams &mp,
                          dim3 grid, hipStream_t s)
@@ -117,11 +132,21 @@ static void launch_col_l(int logN1, bool inverse, bool half_in, const ColArgs<MM
     }
 }
 
+// products per column tile and operand in a walking forward launch (0: never walk)
+static unsigned walk_cap()
+{
+    static const unsigned cap = [] { const char *e = std::getenv("NTT_AMD_COL_GRIDY"); return e ? (unsigned)std::atoi(e) : 16u; }();
+    return cap;
+}
+
 bool launch_col_u64in(bool lazy, int logN1, const void *args, const ModParams &mp, unsigned cols_per_row, unsigned batch,
                       unsigned nops, hipStream_t s)
 {
-    const dim3 grid(cols_per_row / 256, batch, nops);
-    const auto &a = *static_cast<const ColArgs<Mont32> *>(args);
+    dim3 grid(cols_per_row / 256, batch, nops);
+    auto a = *static_cast<const ColArgs<Mont32> *>(args);
+    const unsigned cap = walk_cap();
+    a.loop_batch = cap && batch > cap ? batch : 0;
+    if (a.loop_batch) grid.y = cap;
     if (logN1 == 6 && lazy) hipLaunchKernelGGL((col_kernel<Mont32, true, 6, false, true, true>), grid, dim3(256), 0, s, a, mp);
     else if (logN1 == 6) hipLaunchKernelGGL((col_kernel<Mont32, false, 6, false, true, true>), grid, dim3(256), 0, s, a, mp);
     else if (logN1 == 5 && lazy) hipLaunchKernelGGL((col_kernel<Mont32, true, 5, false, true, true>), grid, dim3(256), 0, s, a, mp);
@@ -135,12 +160,21 @@ void launch_col(int kind, bool lazy, int logN1, bool inverse, bool half_in, cons
                 hipStream_t s)
 {
     dim3 grid(cols_per_row / 256, batch, nops);
+    // Forward passes of 32 / 64 points walk the batch: 16 workgroups per column tile and operand, each taking every
+    // 16th product with its columns' 4-step twiddles loaded once (the compiler hoists the 31 / 63 table loads out
+    // of the loop) -- 537 -> 547 k products/s at the headline shape, profiles/ab_gridy_r02.txt; fewer or more
+    // workgroups, the 16-point levels (RNS shape) and the LDS-staged kernel do not gain.  NTT_AMD_COL_GRIDY=0: off.
+    const unsigned cap = walk_cap();
+    const bool walk = cap && batch > cap && !inverse && logN1 >= 5;
+    if (walk) grid.y = cap;
     if (kind == 0) {
-        const auto &a = *static_cast<const ColArgs<Mont32> *>(args);
+        auto a = *static_cast<const ColArgs<Mont32> *>(args);
+        a.loop_batch = walk ? batch : 0;
         if (lazy) launch_col_l<Mont32, true>(logN1, inverse, half_in, a, mp, grid, s);
         else launch_col_l<Mont32, false>(logN1, inverse, half_in, a, mp, grid, s);
     } else {
-        const auto &a = *static_cast<const ColArgs<Barrett32> *>(args);
+        auto a = *static_cast<const ColArgs<Barrett32> *>(args);
+        a.loop_batch = walk ? batch : 0;
         if (lazy) launch_col_l<Barrett32, true>(logN1, inverse, half_in, a, mp, grid, s);
         else launch_col_l<Barrett32, false>(logN1, inverse, half_in, a, mp, grid, s);
     }
