@@ -93,7 +93,8 @@ def main():
         out.write("\nVALU instr per SIMD-cycle = SQ_INSTS_VALU / SQ_BUSY_CYCLES / 32 (SQ_BUSY_CYCLES is summed over the 32 shader "
                   "engines of 8 CUs x 4 SIMDs; SQ_ACTIVE_INST_VALU reads identical to SQ_INSTS_VALU on this stack, so it is not a "
                   "cycle count).  The butterfly mix peaks at 1 / 3.8 = 0.263 (profiles/ubench_mix_r02.txt); the counter passes run "
-                  "with the profiler serialising the kernels, i.e. every kernel alone on the chip.\n")
+                  "with the profiler serialising the kernels, i.e. every kernel alone on the chip.  A wave of col_kernel_fwd walks the "
+                  "batch (16 workgroups per column tile): its per-wave figures cover 46.5 / 16 = 2.9 products.\n")
     print(open(os.path.join(dst, f"{tag}_summary.md")).read())
     # profiles/traffic.json feeds bench.py's roofline.traffic: PMC bytes per product and kernel of THIS build
     # (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md "HBM"), stamped with the sha256 of the kernel sources

@@ -34,7 +34,9 @@ FULL_RATE = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", 
              "v_cndmask_b32", "v_not_b32", "v_add_f32", "v_fma_f32", "v_accvgpr_read_b32", "v_accvgpr_write_b32",
              "v_nop"}
 
-# (listing, substring of the mangled kernel name, SQ key in the profile summary, waves per product)
+UNITS_PER_LAUNCH = 1024 / 22.0          # bench.py's default batch in 22 launches (tools/profile.sh)
+
+# (listing, substring of the mangled kernel name, SQ key in the profile summary, waves per product and pass)
 KERNELS = {
     "col_fwd": ("kernels_col.hip", "col_kernelINS_6Mont32ELb1ELi6ELb0ELb1ELb0E", "col_kernel_fwd", 2 * 4096 / 64),
     "row_mul": ("kernels_row.hip", "row_mul_kernelINS_6Mont32ELb1E", "row_mul_kernel", 64 * 256 / 64),
@@ -80,16 +82,17 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         for name, (src, key, sqkey, waves) in KERNELS.items():
             n_static, cyc_static, valu = mix(listing(src, tmp), key)
-            n_dyn = n_static
-            if summary and sqkey in summary and summary[sqkey].get("SQ_WAVES"):
-                n_dyn = summary[sqkey]["SQ_INSTS_VALU"] / summary[sqkey]["SQ_WAVES"]
-            cyc = cyc_static / n_static * n_dyn
+            # wave instructions per product: from the counters, SQ_INSTS_VALU of a launch / the products it holds
+            # (a wave of the batch-walking forward column pass serves several products, so per-wave figures do
+            # not convert); without counters, the static count of one pass through the kernel x its waves
+            per_product = n_static * waves
+            if summary and sqkey in summary and summary[sqkey].get("SQ_INSTS_VALU"):
+                per_product = summary[sqkey]["SQ_INSTS_VALU"] / UNITS_PER_LAUNCH
             out["kernels"][name] = {
-                "valu_insts_per_wave_static": n_static, "valu_insts_per_wave": n_dyn,
+                "valu_insts_per_wave_static": n_static, "valu_insts_per_product": per_product,
                 "issue_cycles_per_valu_inst": cyc_static / n_static,
-                "waves_per_product": waves,
-                "issue_cycles_per_product": cyc * waves,
-                "lane_ops_per_product": n_dyn * waves * 64,
+                "issue_cycles_per_product": cyc_static / n_static * per_product,
+                "lane_ops_per_product": per_product * 64,
                 "top_ops": dict(sorted(valu.items(), key=lambda kv: -kv[1])[:8]),
             }
     json.dump(out, open(os.path.join(ROOT, "profiles", "valu_model.json"), "w"), indent=1)
