@@ -59,6 +59,20 @@ static int make_consts(uint64_t p64, CrtConsts &cc)
     cc.nprime64 = 0 - inv;
     for (int k = 0; k < 4; ++k)
         cc.mR[k] = (uint64_t)((((unsigned __int128)(kCrtMods[k] % p64)) << 64) % p64);
+    cc.fast = p64 >= (1ULL << 33) ? 1u : 0u;
+    unsigned __int128 prod = 1;                          // m_0 ... m_(k-1) mod p64
+    for (int k = 0; k < 4; ++k) {
+        cc.c64[k] = (uint64_t)(((prod % p64) << 64) % p64);
+        prod = (prod % p64) * (kCrtMods[k] % p64) % p64;
+    }
+    for (int i = 0; i < 4; ++i)
+        for (int j = i + 1; j < 4; ++j) {
+            // digit i is below m_i; (acc - digit + off) with acc < m_j must stay below 2^32
+            const uint64_t mi = kCrtMods[i], mj = kCrtMods[j];
+            const uint64_t off = (mi - 1 + mj - 1) / mj * mj;      // smallest multiple of m_j that is >= m_i - 1
+            if (off + mj - 1 > 0xffffffffULL) cc.fast = 0;
+            cc.off[i][j] = (uint32_t)off;
+        }
     return NTT_OK;
 }
 

@@ -105,6 +105,13 @@ struct CrtConsts {
     Barrett32::tw_t inv[4][4];           // inv[i][j] = m_i^-1 mod m_j (i < j), Shoup form mod m_j
     uint64_t p64, nprime64;              // target modulus (odd, < 2^63), -p64^-1 mod 2^64
     uint64_t mR[4];                      // m_k * 2^64 mod p64
+    // fast merge (crt_device.hpp): off[i][j] = the multiple of m_j just above m_i - 1 (a Garner step then needs no
+    // reduction of the digit it subtracts); c64[k] = m_0 ... m_(k-1) * 2^64 mod p64 (c64[0] = 2^64 mod p64): the
+    // mixed-radix digits are summed as one 96-bit integer and reduced by two 32-bit Montgomery steps.
+    // fast = 1 when p64 >= 2^33 and every offset keeps its step below 2^32 (true for the reference's primes)
+    uint32_t off[4][4];
+    uint64_t c64[4];
+    uint32_t fast;
 };
 
 // A launch_* dispatcher that has no kernel for the shape it is asked for launches nothing and records it

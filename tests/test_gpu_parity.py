@@ -496,6 +496,30 @@ def test_crt_vs_oracle_large(ctx):
     assert np.array_equal(ctx.crt_multiply(a, b, p64), want)
 
 
+def test_crt_merge_moduli_of_every_size(ctx):
+    """The merge takes two routes (crt_device.hpp): p64 >= 2^33 sums the mixed-radix digits as one 96-bit integer
+    and reduces with two 32-bit Montgomery steps, smaller moduli keep Horner with 64-bit Montgomery products.  Moduli
+    of 20 to 58 bits (need not be prime), extreme coefficients, against Python big-int schoolbook; the exactness guard
+    n (p64 - 1)^2 < M bounds what n may be."""
+    rng = np.random.default_rng(58)
+    M = 1004535809 * 1224736769 * 469762049 * 998244353
+    for p64 in (1048573, (1 << 31) - 1, (1 << 32) + 15, (1 << 33) - 9, (1 << 33) + 17, (1 << 40) + 15, 263882790666241,
+                1337006139375617, (1 << 51) - 129, (1 << 55) + 3, (1 << 58) - 27):
+        n = 6
+        while (n + 1) * (p64 - 1) ** 2 < M and n < 40:
+            n += 1
+        a = rng.integers(0, p64, size=n, dtype=np.uint64)
+        b = rng.integers(0, p64, size=n, dtype=np.uint64)
+        a[0] = b[0] = a[-1] = p64 - 1
+        b[-1] = 0
+        want = [0] * (2 * n - 1)
+        for i in range(n):
+            for j in range(n):
+                want[i + j] = (want[i + j] + int(a[i]) * int(b[j])) % p64
+        got = ctx.crt_multiply(a, b, p64)
+        assert [int(x) for x in got] == want, p64
+
+
 def test_crt_batched(ctx, crt_vectors):
     """ntt_crt_multiply_batched: host and device arrays, every row against the single-product call and the
     oracle; switching between batch sizes and back to single products reuses / rebuilds the cached plans."""
