@@ -133,3 +133,54 @@ def test_config4_rns_32_limbs_x_256():
     lin.close()
     ring.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("shape", ["linear-8192", "linear-5000", "negacyclic-8192"])
+def test_one_kernel_products_at_full_batch(shape):
+    """The one-kernel products (seq_product_kernel, kernels_fused.hip: L = 16384 and the full-length L = 8192) at the
+    batch the size sweep times them with (4096 device-resident products, one workgroup each): every row by the
+    evaluation identity -- linear: A(x) B(x) = AB(x); negacyclic: at the roots of x^n + 1, the odd powers of a 2n-th
+    root --, three rows against the oracle."""
+    import torch
+    import ntt_amd
+
+    kind, n = shape.split("-")
+    n, B, p = int(n), 4096, 998244353
+    neg = kind == "negacyclic"
+    rng = np.random.default_rng(n + neg)
+    ha = rng.integers(0, p, size=(B, n), dtype=np.int64).astype(np.uint32)
+    hb = rng.integers(0, p, size=(B, n), dtype=np.int64).astype(np.uint32)
+    ha[0, :] = p - 1
+    hb[0, :] = p - 1
+    a = torch.from_numpy(ha.view(np.int32)).cuda()
+    b = torch.from_numpy(hb.view(np.int32)).cuda()
+    out_len = n if neg else 2 * n - 1
+    stride = out_len + 1
+    ab = torch.full((B, stride), -1, dtype=torch.int32, device="cuda")
+    ctx = ntt_amd.Context(0)
+    plan = ctx.negacyclic_plan(p, n, B) if neg else ctx.plan(p, n, B)
+    plan.multiply(a, b, out=ab, batch=B, out_stride=stride)
+    ctx.synchronize()
+    plan.close()
+    ctx.close()
+    assert bool((ab[:, out_len:] == -1).all())                    # beyond the product: not ours
+    if neg:
+        # x^n = -1 at x = psi^(2k+1): there the negacyclic product evaluates like the plain one
+        g = 3
+        psi = pow(g, (p - 1) // (2 * n), p)
+        assert int(ab[:, :out_len].max()) < p and int(ab[:, :out_len].min()) >= 0
+        for k in (0, 1, int(rng.integers(2, n))):
+            pw = _powers(pow(psi, 2 * k + 1, p), n, p, torch)
+            ea, eb, eab = _eval_rows(a, pw, p, torch), _eval_rows(b, pw, p, torch), _eval_rows(ab[:, :n], pw, p, torch)
+            bad = torch.nonzero(ea * eb % p != eab).flatten().tolist()
+            assert not bad, (k, bad[:8])
+    else:
+        _check_rows(a, b, ab, out_len, p, torch, rng)
+    got = ab.cpu().numpy().view(np.uint32)
+    for r in (0, B // 2 + 1, B - 1):
+        want = np.asarray(orc.poly_multiply(ha[r], hb[r], p)).astype(np.int64)
+        if neg:
+            hi = np.zeros(n, dtype=np.int64)
+            hi[:n - 1] = want[n:]
+            want = (want[:n] - hi) % p
+        assert np.array_equal(got[r, :out_len], want.astype(np.uint32)), r
