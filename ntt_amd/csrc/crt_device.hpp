@@ -83,10 +83,18 @@ __device__ __forceinline__ uint64_t crt_merge_fast(uint32_t r0v, uint32_t r1v, u
     return x >= cc.p64 ? x - cc.p64 : x;
 }
 
+__device__ __forceinline__ uint64_t crt_merge_slow(uint32_t r0v, uint32_t r1v, uint32_t r2v, uint32_t r3v, const CrtConsts &cc);
+
 // CRT(r0, r1, r2, r3) mod p64 for canonical residues r_k in [0, m_k): the value of main-openmp.cc:473-484
 __device__ __forceinline__ uint64_t crt_merge_value(uint32_t r0v, uint32_t r1v, uint32_t r2v, uint32_t r3v, const CrtConsts &cc)
 {
     if (cc.fast) return crt_merge_fast(r0v, r1v, r2v, r3v, cc);                 // wave-uniform
+    return crt_merge_slow(r0v, r1v, r2v, r3v, cc);
+}
+
+// Horner over 64-bit Montgomery products: any odd p64 < 2^63 (the route of moduli below 2^33)
+__device__ __forceinline__ uint64_t crt_merge_slow(uint32_t r0v, uint32_t r1v, uint32_t r2v, uint32_t r3v, const CrtConsts &cc)
+{
     // Garner: x = v0 + m0 * (v1 + m1 * (v2 + m2 * v3)), v_j in [0, m_j)
     const uint32_t v0 = r0v;
     const uint32_t v1 = garner_step(r1v, v0, cc.inv[0][1], cc.prime[1]);

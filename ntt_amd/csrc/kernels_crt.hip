@@ -35,15 +35,22 @@ __global__ void __launch_bounds__(256) crt_colinv_merge_kernel(const CrtInvArgs 
     run(std::true_type{}, 2);
     run(std::true_type{}, 3);
     const bufrsrc_t rout = make_buf(a.out + (size_t)blockIdx.y * a.out_stride, a.out_len * 8u);
+    // the route is chosen OUTSIDE the unrolled loop: with both bodies inside, the loop is no longer unrolled and the
+    // residue arrays are indexed dynamically, i.e. live in scratch memory
+    auto merge_all = [&](auto fast_tag) {
 #pragma unroll
-    for (int idx = 0; idx < KA * R; ++idx) {
-        const uint64_t v = crt_merge_value(res[0][idx], res[1][idx], res[2][idx], res[3][idx], a.cc);
-        using u32x2 = uint32_t __attribute__((ext_vector_type(2)));
-        u32x2 w;
-        w[0] = (uint32_t)v;
-        w[1] = (uint32_t)(v >> 32);
-        __builtin_amdgcn_raw_buffer_store_b64(w, rout, (int)(off[idx] * 8u), 0, NTT_NT_AUX);   // beyond out_len: dropped
-    }
+        for (int idx = 0; idx < KA * R; ++idx) {
+            const uint64_t v = decltype(fast_tag)::value ? crt_merge_fast(res[0][idx], res[1][idx], res[2][idx], res[3][idx], a.cc)
+                                                         : crt_merge_slow(res[0][idx], res[1][idx], res[2][idx], res[3][idx], a.cc);
+            using u32x2 = uint32_t __attribute__((ext_vector_type(2)));
+            u32x2 w;
+            w[0] = (uint32_t)v;
+            w[1] = (uint32_t)(v >> 32);
+            __builtin_amdgcn_raw_buffer_store_b64(w, rout, (int)(off[idx] * 8u), 0, NTT_NT_AUX);   // beyond out_len: dropped
+        }
+    };
+    if (a.cc.fast) merge_all(std::true_type{});
+    else merge_all(std::false_type{});
 }
 
 bool launch_crt_colinv_merge(int logN1, const CrtInvArgs &a, unsigned cols_per_row, unsigned batch, hipStream_t s)

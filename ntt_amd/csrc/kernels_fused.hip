@@ -9,10 +9,11 @@
 // negacyclic twist folded into (psi w_L^k1)^i), so nothing of the other rows is kept --, runs row_forward x2 /
 // pointwise / row_inverse (row_body.hpp, the body of row_mul_kernel), multiplies by the inverse level's twiddle
 // and parks the 16 results; after the last row the N1-point inverse, scale, inverse twist, canonical store and
-// the 2n-1 cut finish in registers.  N1 - 1 parked rows + two live ones: 94 - 114 VGPRs, four workgroups per
-// CU; the row loop stays rolled (one copy of the row body in the instruction cache).  The operands are read
-// N1 times (from L1 / L2 after the first) and the product written once; nothing else touches memory.  Same row
-// tables and inverse twiddles as the three-kernel path, same results.
+// the 2n-1 cut finish in registers.  N1 - 1 parked rows + two live ones: 94 - 123 VGPRs, four workgroups per CU
+// (at N1 = 4 the compiler parks the rows in scratch memory, 208 B per thread, which measures faster than holding
+// them in registers: see seq_row); the row loop stays rolled (one copy of the row body in the instruction cache).
+// The operands are read N1 times (from L1 / L2 after the first) and the product written once.  Same row tables and
+// inverse twiddles as the three-kernel path, same results.
 //
 // Serves (profiles/time_medium_r02.txt, us per product, three kernels -> this kernel): linear products of
 // 2048 < n <= 4096 (L = 8192, upper half zero: 0.077 -> 0.044) and 4096 < n <= 8192 (L = 16384: 0.137 -> 0.113),
@@ -107,6 +108,9 @@ __device__ __forceinline__ void seq_row(const int k1, uint32_t (&xa)[16], uint32
     fused_row<MM, LAZY>(xa, xb, lds, tt, a.r.row, m);
 #pragma unroll
     for (int j = 0; j < 16; ++j) xa[j] = O::mul_tw(xa[j], a.tw_inv[(uint32_t)k1 * kRowLen + tt + 256u * j], m);
+    // (N1 = 4: the compiler turns these wave-uniform copies into one dynamically addressed store, i.e. the rows are
+    // parked in scratch memory; forcing them into registers with selects -- 128 VGPRs -- is 17 - 30 % slower:
+    // 0.135 vs 0.116 us at L = 16384, 0.072 vs 0.056 us at the full-length L = 8192 with its one parked row)
 #pragma unroll
     for (int q = 0; q < N1 - 1; ++q)
         if (k1 == q) {                                    // wave-uniform
