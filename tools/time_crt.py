@@ -1,7 +1,7 @@
 import sys, time
 import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, R + '/tests')
 import numpy as np, torch, ntt_amd
-p64, n, B = 1337006139375617, 131072, 64
+p64, n, B = 1337006139375617, 131072, int(os.environ.get("CRT_B", "64"))
 ctx = ntt_amd.Context(0)
 rng = np.random.default_rng(1)
 a = torch.from_numpy(rng.integers(0, p64, size=(B, n), dtype=np.uint64).view(np.int64)).cuda()
