@@ -103,8 +103,13 @@ int ntt_poly_multiply_batched(ntt_plan *plan, const uint32_t *a, const uint32_t 
  *     the products go through the scratch array in groups of floor(64 MiB / (8 L)));
  *   - one stream (the context's), no kernel-timing events; the call makes no hipMalloc / hipFree / event or
  *     stream creation.  Asynchronous: results are complete after ntt_ctx_synchronize;
- *   - every call on a GPU shares that GPU's scratch array: calls that overlap in time on one GPU (two contexts,
- *     or one context whose stream the caller changed between calls without ordering them) race.
+ *   - every call on a GPU shares that GPU's scratch array.  The library orders the calls of one PROCESS on a GPU
+ *     itself: a per-device event marks the end of the last call there, each call makes its stream wait on it first and
+ *     records it behind its last kernel (no allocation: the event exists since ntt_ctx_create), so two contexts, or
+ *     one context whose stream changed between calls, serialise on the array in call order instead of racing.
+ *     What the library cannot see still races: a second process on the same GPU has its own copy (no conflict), but
+ *     work under HIP graph replay that was captured from this call runs without the wait and must not overlap
+ *     another call on that GPU.
  * Not for negacyclic plans. */
 int ntt_poly_multiply_batched_noalloc(ntt_plan *plan, const uint32_t *a, const uint32_t *b, uint32_t *ab,
                                       size_t ab_stride, int batch);

@@ -39,6 +39,14 @@ void crt_release(ntt_ctx *ctx)
     w.batch = 0;
 }
 
+void crt_direct_release(ntt_ctx *ctx)               // context teardown only
+{
+    if (ctx->crt_direct.plan) {
+        ntt_plan64_destroy(ctx->crt_direct.plan);
+        ctx->crt_direct.plan = nullptr;
+    }
+}
+
 static int make_consts(uint64_t p64, CrtConsts &cc)
 {
     for (int k = 0; k < 4; ++k) {
@@ -107,6 +115,29 @@ try {
             return fail(NTT_ERR_UNSUPPORTED, "ntt_crt_multiply: n * p64^2 exceeds the product of the four CRT primes");
     }
     if (n > (1 << 22)) return fail(NTT_ERR_UNSUPPORTED, "ntt_crt_multiply: n too large for the 2^23-adic prime 998244353");
+    // Route: when p64 is itself a prime with L | p64 - 1 (the reference's 1337006139375617 = 19 * 2^46 + 1 is), ONE
+    // transform with 64-bit lanes gives the same canonical coefficients as four residue products and a merge -- both
+    // are the exact product reduced mod p64 -- in half the time (5.5 vs 10.8 us per n = 2^17 product in a batch;
+    // tests/test_gpu_direct64.py::test_direct64_matches_crt_path_on_gpu).  NTT_AMD_CRT_DIRECT=0 (read per call) keeps
+    // the four-prime path, which every other modulus takes anyway.
+    {
+        const char *e = std::getenv("NTT_AMD_CRT_DIRECT");
+        uint64_t L = 2;
+        while (L < 2 * (uint64_t)n) L <<= 1;
+        if (!(e && e[0] == '0') && (p64 - 1) % L == 0 && ((uint64_t)batch * L) <= (1ull << 29) && batch <= 65535 &&
+            is_prime64(p64)) {
+            auto &d = ctx->crt_direct;
+            std::lock_guard<std::mutex> dl(d.mu);
+            if (!d.plan || d.p != p64 || d.n != n || d.batch < batch) {
+                if (d.plan) ntt_plan64_destroy(d.plan);
+                d.plan = nullptr;
+                const int rc = ntt_plan64_create(ctx, p64, n, batch, &d.plan);
+                if (rc) return rc;
+                d.p = p64; d.n = n; d.batch = batch;
+            }
+            return ntt_poly_multiply64_batched(d.plan, a, b, ab, 2 * (size_t)n - 1, batch);
+        }
+    }
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     CrtWorkspace &w = ctx->crt;
@@ -146,7 +177,8 @@ try {
     const uint32_t L = w.plans[0]->wide ? w.plans[0]->wide->L : w.plans[0]->L;
     const bool needs_area = w.plans[0]->logL > kRowLog && !w.plans[0]->fused && !w.plans[0]->wide;
     if (batch >= 4 && ctx->nlanes > 1 && ctx->lane[1] && ctx->lane_limit != 1 && needs_area) {
-        static const int group_max = [] { const char *e = std::getenv("NTT_AMD_CRT_GROUP"); return e ? std::max(1, std::atoi(e)) : 32; }();
+        // (both switches are read per call, so that a test can A/B the routes in one process)
+        const int group_max = [] { const char *e = std::getenv("NTT_AMD_CRT_GROUP"); return e ? std::max(1, std::atoi(e)) : 32; }();
         int ngroups = (batch + group_max - 1) / group_max;
         if (ngroups & 1) ++ngroups;                        // the same number of groups on both lanes
         const int G = (batch + ngroups - 1) / ngroups;
@@ -154,12 +186,15 @@ try {
         // has for 32 or 64 points (L = 2^17, 2^18), the residue products stop in front of their last inverse column
         // pass, each prime's row output stays in a work array of its own, and ONE kernel runs that pass for the four
         // primes and merges -- the residues never travel through memory.  NTT_AMD_CRT_FUSE=0 keeps the separate kernels.
-        static const bool fuse_ok = [] { const char *e = std::getenv("NTT_AMD_CRT_FUSE"); return !(e && e[0] == '0'); }();
+        const bool fuse_ok = [] { const char *e = std::getenv("NTT_AMD_CRT_FUSE"); return !(e && e[0] == '0'); }();
         bool fuse = fuse_ok;
         for (int k = 0; k < 4; ++k) {
             const ntt_plan *pk = w.plans[k];
             fuse = fuse && pk->kind == NTT_MODMUL_MONTGOMERY && pk->nlevels >= 1 && (pk->level_log[0] == 5 || pk->level_log[0] == 6) &&
-                   pk->L == L && pk->tw_in_inv[0].size() >= 64 * sizeof(uint32_t);
+                   pk->L == L && pk->tw_in_inv[0].size() >= 64 * sizeof(uint32_t) &&
+                   // crt_colinv_merge_kernel runs the lazy body for the primes below 2^30 and the strict one for
+                   // 1224736769, in kCrtMods order (kernels_crt.hip): a plan whose policy differs keeps the separate kernels
+                   pk->lazy == (kCrtMods[k] < (1u << 30));
         }
         // Fused head: the same shapes read the caller's u64 operands in the first forward column pass of every prime and
         // reduce them there (col_kernel<..., U64IN>), so the reduce sweep and its residue arrays drop out as well.

@@ -58,7 +58,7 @@ uint64_t powmod(uint64_t b, uint64_t e, uint64_t p)
     return r;
 }
 // deterministic Miller-Rabin for 64-bit integers (the first twelve primes as bases)
-bool is_prime64(uint64_t n)
+bool is_prime64_impl(uint64_t n)
 {
     if (n < 2) return false;
     for (uint64_t q : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
@@ -329,6 +329,11 @@ int multiply_device(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64
 }
 
 }  // namespace
+
+namespace ntt {
+bool is_prime64(uint64_t n) { return is_prime64_impl(n); }
+}
+using ntt::is_prime64;
 
 static int plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, bool negacyclic, ntt_plan64 **out);
 

@@ -24,6 +24,13 @@
 // like every other use of the memory, get that pointer, never the name.
 static constexpr size_t kScratchBytes = (size_t)64 << 20;
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+// Every context on a GPU shares that GPU's copy of the array.  Calls are ordered per DEVICE, not per context: one
+// event per device marks the end of the last noalloc call there (created in ntt_ctx_create, so the call itself still
+// creates nothing); a call makes its stream wait on it before the first kernel touches the array and records it behind
+// the last one.  g_scratch_mu keeps the wait / launch / record sequences of two host threads from interleaving.
+static constexpr int kMaxScratchDevices = 64;
+static std::mutex g_scratch_mu;
+static hipEvent_t g_scratch_last[kMaxScratchDevices] = {};
 
 namespace ntt {
 
@@ -733,15 +740,19 @@ try {
         return fail(NTT_ERR_UNSUPPORTED, std::string("ntt_ctx_create: kernels are built for gfx950, device is ") + prop.gcnArchName);
     auto *cx = new ntt_ctx();
     cx->device = dev;
-    {   // this device's copy of the scratch array (device `dev` is current): its address, never the array's name
+    {   // this device's copy of the scratch array (device `dev` is current): its address, never the array's name.
+        // A failed lookup leaves cx->scratch null: only ntt_poly_multiply_batched_noalloc then reports unsupported.
         void *sp = nullptr;
         const hipError_t se = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
-        if (se != hipSuccess || !sp) {
-            delete cx;
-            return fail(NTT_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(se));
+        if (se != hipSuccess) (void)hipGetLastError();
+        std::lock_guard<std::mutex> sl(g_scratch_mu);
+        if (se == hipSuccess && sp && dev < kMaxScratchDevices &&
+            (g_scratch_last[dev] || hipEventCreateWithFlags(&g_scratch_last[dev], hipEventDisableTiming) == hipSuccess)) {
+            cx->scratch = sp;
+            cx->scratch_bytes = kScratchBytes;
+        } else {
+            (void)hipGetLastError();
         }
-        cx->scratch = sp;
-        cx->scratch_bytes = kScratchBytes;
     }
     hipError_t e = hipStreamCreateWithFlags(&cx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -848,6 +859,7 @@ try {
     for (auto &kv : ctx->plan_cache) ntt_plan_destroy(kv.second);
     ctx->plan_cache.clear();
     ntt::crt_release(ctx);
+    ntt::crt_direct_release(ctx);
     ntt::stream_release(ctx);
     ctx->stage_a.release();
     ctx->stage_b.release();
@@ -1098,11 +1110,26 @@ try {
         area.w0 = static_cast<uint32_t *>(cx->scratch);
         area.w1 = area.w0 + (size_t)area.chunk * shape->L;
     }
-    const bool timing = cx->timing;                        // stamping a launch may create events: not on this path
-    cx->timing = false;
+    struct TimingOff {                                     // stamping a launch may create events: not on this path
+        ntt_ctx *c;
+        bool was;
+        explicit TimingOff(ntt_ctx *cx_) : c(cx_), was(cx_->timing) { c->timing = false; }
+        ~TimingOff() { c->timing = was; }
+    } timing_off(cx);
+    // the scratch array belongs to the device: order this call behind the last one that used it there, whichever context
+    // and stream that was, and leave the mark for the next
+    const bool uses_scratch = area.w0 != nullptr;
+    std::unique_lock<std::mutex> sl(g_scratch_mu, std::defer_lock);
+    if (uses_scratch) {
+        sl.lock();
+        HIP_TRY(hipStreamWaitEvent(cx->stream, g_scratch_last[cx->device], 0));
+    }
     const int rc = pl->kind == NTT_MODMUL_MONTGOMERY ? multiply_device<Mont32>(pl, a, b, ab, ab_stride, batch, &area)
                                                      : multiply_device<Barrett32>(pl, a, b, ab, ab_stride, batch, &area);
-    cx->timing = timing;
+    if (uses_scratch) {                                    // also after a failure: what was launched still uses the array
+        const hipError_t re = hipEventRecord(g_scratch_last[cx->device], cx->stream);
+        if (re != hipSuccess && rc == NTT_OK) return fail(NTT_ERR_HIP, std::string("hipEventRecord(scratch order): ") + hipGetErrorString(re));
+    }
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return take_launch_error();

@@ -10,6 +10,7 @@
 #include "kernels.hpp"
 
 struct ntt_plan;
+struct ntt_plan64;
 struct ntt_ctx;
 
 namespace ntt {
@@ -41,12 +42,14 @@ struct CrtWorkspace {
     DeviceBuffer area;                    // work areas of the grouped batch (crt.cpp): 2 lanes x 2 operands x group x L words
 };
 void crt_release(ntt_ctx *ctx);
+void crt_direct_release(ntt_ctx *ctx);
 struct StreamState;                       // stream.cpp: ring of device slots + copy streams
 void stream_release(ntt_ctx *ctx);
 const char *last_error_cstr();
 // NTT_OK, or NTT_ERR_INTERNAL (and the message) if a dispatcher skipped a launch since the last call; clears the mark
 int take_launch_error();
 bool is_device_ptr(const void *p);
+bool is_prime64(uint64_t n);              // direct64.cpp: deterministic Miller-Rabin
 
 // Where a multiply keeps the intermediates of its passes when they are not the plan's own work buffers:
 // room for `chunk` products (w0 / w1: chunk * L words each); the multiply then runs on ONE stream (ctx->stream).
@@ -105,6 +108,14 @@ struct ntt_ctx {
     // caches owned by the context
     std::map<std::array<uint64_t, 3>, ntt_plan *> plan_cache;     // (p, n, kind): poly_multiply / CRT
     ntt::CrtWorkspace crt;
+    // ntt_crt_multiply[_batched] for a modulus that is itself an NTT-friendly prime for the length: the direct 64-bit
+    // plan (direct64.cpp) gives the same canonical coefficients in half the time; cached for the last (p64, n) used
+    struct CrtDirect {
+        std::mutex mu;                                // held across a routed call (the plan may be rebuilt by the next)
+        ntt_plan64 *plan = nullptr;
+        uint64_t p = 0;
+        int n = 0, batch = 0;
+    } crt_direct;
     ntt::DeviceBuffer stage_a, stage_b, stage_out;   // host-pointer staging
     ntt::StreamState *stream_state = nullptr;        // ntt_poly_multiply_stream (stream.cpp)
 };

@@ -253,7 +253,10 @@ __global__ void __launch_bounds__(256) crt_merge_kernel(const uint32_t *__restri
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    out[i] = crt_merge_value(r0[i], r1[i], r2[i], r3[i], cc);
+    // the public ntt_crt_merge takes residues from the caller: one reduction each makes any u32 acceptable (the fast
+    // Garner steps of crt_device.hpp assume r_k < m_k; the fused kernel's residues are canonical by construction)
+    out[i] = crt_merge_value(red32(r0[i], cc.prime[0]), red32(r1[i], cc.prime[1]), red32(r2[i], cc.prime[2]),
+                             red32(r3[i], cc.prime[3]), cc);
 }
 
 void launch_crt_merge(const uint32_t *const res[4], uint64_t *out, size_t n, const CrtConsts &cc,

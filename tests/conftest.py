@@ -65,3 +65,13 @@ def lanes64(request, monkeypatch):
     else:
         monkeypatch.delenv("NTT_AMD_PLAN64_INT", raising=False)
     return request.param
+
+
+@pytest.fixture(autouse=True)
+def crt_four_prime_route(monkeypatch):
+    """ntt_crt_multiply[_batched] sends a modulus that is itself an NTT-friendly prime for the length (the
+    reference's 1337006139375617 is) through the direct 64-bit plan by default (crt.cpp).  The CRT tests exist to
+    check the FOUR-PRIME path -- residue products, Garner merge (main-openmp.cc:424-485) -- so every test runs with
+    NTT_AMD_CRT_DIRECT=0 (read per call) unless it asks for the default route itself
+    (tests/test_gpu_round3.py::test_crt_multiply_routes_to_direct_plan)."""
+    monkeypatch.setenv("NTT_AMD_CRT_DIRECT", "0")

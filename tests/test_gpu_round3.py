@@ -1,0 +1,190 @@
+"""Round-3 route and test gaps: branches of the CRT batch that no test reached, the
+public merge on non-canonical residues, and the per-device ordering of the no-alloc entry point's scratch array.
+All through the C ABI (ctypes), against the CPU oracle (main-openmp.cc:693-711 restated in oracle/ntt_oracle.c)."""
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+P64 = 1337006139375617                     # the reference's fifth modulus (main-openmp.cc:636)
+
+
+@pytest.fixture(scope="module")
+def nt():
+    import ntt_amd
+    return ntt_amd
+
+
+@pytest.fixture()
+def ctx(nt):
+    c = nt.Context(0)
+    yield c
+    c.close()
+
+
+def _pairs(seed, batch, n):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, P64, size=(batch, n), dtype=np.uint64)
+    b = rng.integers(0, P64, size=(batch, n), dtype=np.uint64)
+    a[0, :] = P64 - 1
+    b[0, :] = P64 - 1
+    return a, b
+
+
+def _check_rows(ctx, a, b, got, oracle_rows):
+    for r in range(a.shape[0]):
+        assert np.array_equal(got[r], ctx.crt_multiply(a[r], b[r], P64)), r      # the separate-kernel single product
+    for r in oracle_rows:
+        want, _ = orc.poly_multiply_crt(a[r], b[r], P64, threads=8)
+        assert np.array_equal(got[r], want), r
+
+
+@pytest.mark.parametrize("n,batch", [(10000, 6), (300000, 5)])
+def test_crt_batch_unfused_grouped_branch(ctx, n, batch):
+    """L = 2^15 (column level of 8 points) and L = 2^20 (a 256-point level): the grouped two-lane CRT batch without the
+    fused head and tail -- reduce_all with the group offset, the two-slot work area, launch_crt_merge on a group slice
+    (crt.cpp) -- every row against the single-product call, first and last row against the oracle."""
+    a, b = _pairs(n, batch, n)
+    got = ctx.crt_multiply_batched(a, b, P64)
+    _check_rows(ctx, a, b, got, (0, batch - 1))
+
+
+def test_crt_batch_fused_tail_without_fused_head(ctx):
+    """A workspace created with batch == 4 keeps the LDS-staged forward column pass (ntt_plan::col16_fwd), so the
+    batch runs with the fused tail but the separate reduce sweep (fuse && !fuse_in in crt.cpp)."""
+    n = 70000
+    a, b = _pairs(4, 4, n)
+    got = ctx.crt_multiply_batched(a, b, P64)
+    _check_rows(ctx, a, b, got, (0, 3))
+
+
+def test_crt_batch_routes_ab_in_one_process(nt, monkeypatch):
+    """NTT_AMD_CRT_FUSE / NTT_AMD_CRT_GROUP are read per call: the same batch through the fused and the unfused route
+    and with groups of 2 gives identical arrays (and the oracle's rows)."""
+    n, batch = 70000, 7
+    a, b = _pairs(7, batch, n)
+    c = nt.Context(0)
+    fused = c.crt_multiply_batched(a, b, P64)
+    monkeypatch.setenv("NTT_AMD_CRT_FUSE", "0")
+    unfused = c.crt_multiply_batched(a, b, P64)
+    monkeypatch.setenv("NTT_AMD_CRT_GROUP", "2")
+    small_groups = c.crt_multiply_batched(a, b, P64)
+    monkeypatch.delenv("NTT_AMD_CRT_FUSE")
+    small_groups_fused = c.crt_multiply_batched(a, b, P64)
+    c.close()
+    assert np.array_equal(fused, unfused) and np.array_equal(fused, small_groups) and np.array_equal(fused, small_groups_fused)
+    for r in (0, batch - 1):
+        want, _ = orc.poly_multiply_crt(a[r], b[r], P64, threads=8)
+        assert np.array_equal(fused[r], want), r
+
+
+def test_crt_merge_takes_any_u32_residue(nt, ctx):
+    """ntt_crt_merge is public: residues that are not canonical (r_k + m_k, where that still fits 32 bits, and the
+    all-ones word) merge to the value of their canonical form (CRT_combine_parallel reduces with %, main-openmp.cc:476)."""
+    rng = np.random.default_rng(5)
+    count = 1000
+    mods = [nt.crt_prime(k) for k in range(4)]
+    canon = [rng.integers(0, m, size=count, dtype=np.int64).astype(np.uint32) for m in mods]
+    want = ctx.crt_merge(canon, P64)
+    loose = []
+    for r, m in zip(canon, mods):
+        x = r.astype(np.uint64) + np.uint64(m) * rng.integers(0, 4, size=count).astype(np.uint64)
+        loose.append(np.where(x < (1 << 32), x, r.astype(np.uint64)).astype(np.uint32))
+    assert any(int((l != c).sum()) > 0 for l, c in zip(loose, canon))
+    assert np.array_equal(ctx.crt_merge(loose, P64), want)
+    # against big integers on a few coefficients
+    M = 1
+    for m in mods:
+        M *= m
+    for i in range(0, count, 97):
+        x = 0
+        for r, m in zip(canon, mods):
+            Mi = M // m
+            x += int(r[i]) * Mi * pow(Mi, -1, m)
+        assert int(want[i]) == x % M % P64
+
+
+def test_noalloc_calls_of_two_contexts_are_ordered(nt):
+    """Two contexts on one GPU share the device's scratch array (engine.cpp): calls issued back to back on their two
+    streams, without any synchronisation between them, must each give the batched entry point's result."""
+    import torch
+    p, n, batch = 998244353, 131072, 24
+    rng = np.random.default_rng(3)
+    c0, c1 = nt.Context(0), nt.Context(0)
+    plans = [c.plan(p, n, batch) for c in (c0, c1)]
+    ops, want, got = [], [], []
+    for i in range(2):
+        a = torch.from_numpy(rng.integers(0, p, size=(batch, n), dtype=np.int64).astype(np.uint32).view(np.int32)).cuda()
+        b = torch.from_numpy(rng.integers(0, p, size=(batch, n), dtype=np.int64).astype(np.uint32).view(np.int32)).cuda()
+        ops.append((a, b))
+        w = torch.zeros((batch, 2 * n - 1), dtype=torch.int32, device="cuda")
+        plans[i].multiply(a, b, out=w, batch=batch)
+        want.append(w)
+        got.append(torch.zeros((batch, 2 * n - 1), dtype=torch.int32, device="cuda"))
+    c0.synchronize()
+    c1.synchronize()
+    torch.cuda.synchronize()
+    for rep in range(3):                                   # six calls in flight, alternating contexts
+        for i in range(2):
+            plans[i].multiply_noalloc(ops[i][0], ops[i][1], got[i], batch)
+    c0.synchronize()
+    c1.synchronize()
+    for i in range(2):
+        assert torch.equal(got[i], want[i]), i
+    row = got[1][batch - 1].cpu().numpy().view(np.uint32)
+    assert np.array_equal(row, orc.poly_multiply(ops[1][0][batch - 1].cpu().numpy().view(np.uint32),
+                                                 ops[1][1][batch - 1].cpu().numpy().view(np.uint32), p))
+    for pl in plans:
+        pl.close()
+    c0.close()
+    c1.close()
+
+
+def test_crt_multiply_routes_to_direct_plan(nt, monkeypatch):
+    """Default route of ntt_crt_multiply[_batched] (crt.cpp): p64 = 1337006139375617 is a prime with 2^46 | p64 - 1,
+    so the product runs as ONE transform with 64-bit lanes; a modulus that is not such a prime keeps the four-prime
+    path.  Same arrays either way, and the oracle's (main-openmp.cc:693-711)."""
+    import torch
+    rng = np.random.default_rng(64)
+    c = nt.Context(0)
+    for n, batch in ((1000, 3), (131072, 5)):
+        a, b = _pairs(n + 1, batch, n)
+        monkeypatch.setenv("NTT_AMD_CRT_DIRECT", "0")
+        four = c.crt_multiply_batched(a, b, P64)
+        monkeypatch.delenv("NTT_AMD_CRT_DIRECT")
+        c.enable_kernel_timing(True)
+        direct = c.crt_multiply_batched(a, b, P64)
+        times = c.kernel_times()
+        c.enable_kernel_timing(False)
+        assert times["crt_merge"][1] == 0 and times["crt_reduce"][1] == 0        # no CRT kernel ran ...
+        assert times["col64"][1] + times["lds64"][1] > 0                           # ... the 64-bit lanes did
+        assert np.array_equal(direct, four)
+        want, _ = orc.poly_multiply_crt(a[0], b[0], P64, threads=8)
+        assert np.array_equal(direct[0], want)
+        assert np.array_equal(c.crt_multiply(a[1], b[1], P64), four[1])           # batch 1 through the cached plan
+        da = torch.from_numpy(a.view(np.int64)).cuda()
+        db = torch.from_numpy(b.view(np.int64)).cuda()
+        out = torch.zeros((batch, 2 * n - 1), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        c.crt_multiply_batched(da, db, P64, out=out)                               # device arrays, asynchronous
+        c.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), four)
+    # 2^51 - 129 is prime but 2^10 does not divide 2^51 - 130; 263882790666241 = 15 * 2^44 + 1 is prime: the first stays on four primes
+    for p64, routed in (((1 << 51) - 129, False), (263882790666241, True)):
+        n = 300
+        a = rng.integers(0, p64, size=n, dtype=np.uint64)
+        b = rng.integers(0, p64, size=n, dtype=np.uint64)
+        c.enable_kernel_timing(True)
+        got = c.crt_multiply(a, b, p64)
+        times = c.kernel_times()
+        c.enable_kernel_timing(False)
+        assert (times["crt_merge"][1] == 0) == routed, p64
+        want = [0] * (2 * n - 1)
+        for i in range(n):
+            ai = int(a[i])
+            for j in range(n):
+                want[i + j] += ai * int(b[j])
+        assert [int(x) for x in got] == [w % p64 for w in want], p64
+    c.close()

@@ -5,6 +5,8 @@ the second runs.  Collected last (file name): it shares the GPU's one scratch ar
 import numpy as np
 import pytest
 
+import orc
+
 pytestmark = pytest.mark.gpu
 
 
@@ -40,6 +42,10 @@ def test_noalloc_entry_matches_batched_entry():
         plan.multiply_noalloc(a, b, got, b1, out_stride=stride)          # first call
         ctx.synchronize()
         assert torch.equal(got, want), (n, b1)
+        # one row against the CPU oracle as well (the batched entry point it is compared with is oracle-checked elsewhere;
+        # this keeps the test from being a self-comparison): the row of extreme operands
+        assert np.array_equal(got[0, :2 * n - 1].cpu().numpy().view(np.uint32),
+                              orc.poly_multiply(a[0].cpu().numpy().view(np.uint32), b[0].cpu().numpy().view(np.uint32), p)), n
         # second call, smaller input: the last rows only, into a fresh output
         a2, b2_ = a[b1 - b2:].contiguous(), b[b1 - b2:].contiguous()
         torch.cuda.synchronize()
