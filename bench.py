@@ -20,6 +20,12 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
                   VALU roofline beside it (the bound DESIGN.md section 5 argues), `kernels_one_lane`
                   = per-kernel time on one stream lane (uncontended), `sustained` = the same step
                   loop over >= 2 s after the timed region (board power settled)
+  also         -- the other sharded workloads of SURVEY 8(e) behind the headline loop, timed the same way (barrier,
+                  synchronise, max over ranks), flat scalars: the prime-per-rank CRT product at n = 2^17
+                  (shard.CrtExchange; main-mpi.cc:706-802), 32 RNS limbs x 256 pairs at n = 2^16 split by limb, one
+                  2^26-point transform forward + inverse split over the ranks (shard.DistExchange); every rank checks
+                  an oracle-free identity, rank 0 one oracle row each.  --no-also skips it; a watchdog prints the line
+                  without it if an exchange hangs
   cpu_baseline -- the CPU oracle's restatement of the reference's OpenMP path (main-openmp.cc) timed
                   on this box's host cores on a bounded sample of the same workload (rank 0, N = 1);
                   this leg is the only place the oracle is touched: it also compares its product of
@@ -54,6 +60,11 @@ SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
 #                                        hand-off buffers and compute nothing: 1.24 us per product (48 per launch, 2 lanes)
 MEASURED_MIX_PEAK_TLANEOPS = 40.6
 MEASURED_TRAFFIC_FLOOR_US = 1.244
+#   profiles/ubench_clock_r02.txt        the same butterfly loop BESIDE a second stream that keeps the memory system as
+#                                        busy as this pipeline does: 33.6 T (Infinity-Cache-resident copy) to 34.6 T
+#                                        (HBM copy) lane-op/s -- the VALU peak the pipeline can reach while it moves
+#                                        its bytes ("coupled" peak; mean of the two)
+COUPLED_MIX_PEAK_TLANEOPS = 34.1
 
 
 def splitmix64(seed, count):
@@ -105,7 +116,7 @@ def usable_cores():
     return limits[name], name, total
 
 
-def cpu_baseline(n, p, budget_s, gpu_row0):
+def cpu_baseline(n, p, budget_s, gpu_row0, with_ref=False):
     """The oracle's port of main-openmp.cc (per-stage block-parallel radix-2 NTT, 64-bit Montgomery),
     timed between the reference's Start/End stamps.  Checker code used as the reported baseline only;
     its product of pair 0 (the same seeds as row 0 of rank 0's batch) is also compared with the GPU's.
@@ -148,7 +159,7 @@ def cpu_baseline(n, p, budget_s, gpu_row0):
         for _ in range(2):
             orc.poly_multiply(a32, b32, p, kind=kind)
         others[f"single_thread_{kind}_ms"] = 1e3 * (time.time() - t1) / 2
-    if orc.have_ref() and p < (1 << 31):
+    if with_ref and orc.have_ref() and p < (1 << 31):
         # the reference's own main-baseline.cc multiply body, compiled in place (oracle/_ref, kind "reference")
         ia, ib = a32.view(np.int32).copy(), b32.view(np.int32).copy()
         iab = np.zeros(2 * n - 1, dtype=np.int32)
@@ -160,6 +171,211 @@ def cpu_baseline(n, p, budget_s, gpu_row0):
             print("bench: GPU result differs from the compiled reference (main-baseline.cc)", file=sys.stderr)
             sys.exit(1)
     out["others_ms_per_product"] = others
+    return out
+
+
+def rns_primes(count, two_adicity, above):
+    """The `count` smallest primes p > above with p = 1 mod 2^two_adicity (SURVEY 8d, configs[3])."""
+    def is_prime(m):
+        d, r = m - 1, 0
+        while d % 2 == 0:
+            d //= 2
+            r += 1
+        for a in (2, 3, 5, 7, 11, 13, 17):             # deterministic below 3.4e14
+            x = pow(a, d, m)
+            if x in (1, m - 1):
+                continue
+            for _ in range(r - 1):
+                x = x * x % m
+                if x == m - 1:
+                    break
+            else:
+                return False
+        return True
+    out, step = [], 1 << two_adicity
+    p = (above // step + 1) * step + 1
+    while len(out) < count:
+        if is_prime(p):
+            out.append(p)
+        p += step
+    return out
+
+
+def _powers_t(torch, x, count, p):
+    """[x^0 .. x^(count-1)] mod p as an int64 device tensor (doubling)."""
+    pw = torch.ones(1, dtype=torch.int64, device="cuda")
+    xk = x % p
+    while pw.numel() < count:
+        pw = torch.cat([pw, pw * xk % p])
+        xk = xk * xk % p
+    return pw[:count]
+
+
+def _eval_rows_t(torch, t, x, p, rows_per_step=64):
+    """Every row of the int32 device tensor t (residues < p < 2^31) evaluated at x, mod p (terms < 2^62, sums < 2^49)."""
+    pw = _powers_t(torch, x, t.shape[1], p)
+    out = []
+    for r0 in range(0, t.shape[0], rows_per_step):
+        out.append(((t[r0:r0 + rows_per_step].to(torch.int64) * pw) % p).sum(dim=1) % p)
+    return torch.cat(out)
+
+
+def _eval_point_t(torch, x, wk, p, blk=1 << 13):
+    """sum x[i] wk^i mod p for a long int32 device vector (length a multiple of blk): one output point of a transform."""
+    pw = _powers_t(torch, wk, blk, p)
+    sums = ((x.view(-1, blk).to(torch.int64) * pw) % p).sum(dim=1) % p
+    pws = _powers_t(torch, pow(wk, blk, p), sums.numel(), p)
+    return int(((sums * pws) % p).sum() % p)
+
+
+def also_block(args, group, rank, world, local_rank):
+    """The sharded workloads of SURVEY 8(e) beside the headline one (flat dict of scalars): (a) BASELINE.json
+    configs[2], the 4-prime CRT product at n = 2^17 with the primes partitioned over the ranks and the slice exchange
+    (main-mpi.cc:657-660, 739-797) through shard.CrtExchange; (b) configs[3], 32 RNS limbs x 256 pairs at n = 2^16, limbs
+    partitioned over the ranks, no exchange; (c) configs[4], one 2^26-point transform forward + inverse split over the
+    ranks through shard.DistExchange (one rank: the single-GPU transform).  Each: milliseconds (max over ranks),
+    algorithmic GB/s, bytes a rank sends per unit.  Every rank checks an oracle-free identity; rank 0 also compares one
+    row / point with the CPU oracle.  Runs on a context of its own (CrtExchange moves it to torch's stream)."""
+    import torch
+    import ntt_amd
+    import orc
+    from ntt_amd import shard
+    out, failed = {}, []
+    on_device = args.backend == "nccl" or group.dist is None
+    ctx = ntt_amd.Context(local_rank)
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    def timed(fn, reps, warm=1):
+        for _ in range(warm):
+            fn()
+        sync()
+        group.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        sync()
+        group.barrier()
+        return group.max_over_ranks(time.perf_counter() - t0) / reps
+
+    # (a) large-modulus product, primes over the ranks + one exchange
+    n, p64 = 131072, 1337006139375617
+    a = splitmix64(0xC47A, n) % np.uint64(p64)
+    b = splitmix64(0xC47B, n) % np.uint64(p64)
+    ta, tb = torch.from_numpy(a.view(np.int64)), torch.from_numpy(b.view(np.int64))
+    if on_device:
+        ta, tb = ta.cuda(), tb.cuda()
+    ex = shard.CrtExchange(group, ctx, n, p64, device="cuda" if on_device else "cpu")
+    got = ex.multiply(ta, tb)
+    sync()
+    got = got.cpu().numpy().view(np.uint64).copy()
+
+    def at(c, sign):                                  # C(1) and C(-1) mod p64 with Python integers
+        v = c.tolist()
+        return (sum(v[0::2]) + sign * sum(v[1::2])) % p64
+    if int(got.max()) >= p64 or any(at(a, s) * at(b, s) % p64 != at(got, s) for s in (1, -1)):
+        failed.append("crt identity")
+    if rank == 0:
+        want, _ = orc.poly_multiply_crt(a, b, p64, threads=usable_cores()[0])
+        if not np.array_equal(got, want):
+            failed.append("crt oracle")
+    t = timed(lambda: ex.multiply(ta, tb), 10)
+    out["crt4_n2p17_ms"] = 1e3 * t
+    out["crt4_GBps"] = (32 * n - 8) / t / 1e9                    # read a, b (u64), write ab (u64)
+    out["crt4_sent_bytes_per_rank"] = (world - 1) * ex.sl * (4 * ex.count + 8)      # residue slices out + u64 slice all-gather
+    out["crt4_primes_per_rank"] = -(-4 // world)
+
+    # (b) RNS limbs over the ranks, no exchange
+    n, limbs, polys = 65536, 32, 256
+    primes = rns_primes(limbs, 17, 1 << 30)
+    start, count = shard.partition(limbs, world, rank)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(4 + rank)
+    ra = torch.randint(0, 1 << 30, (polys, n), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32)
+    rb = torch.randint(0, 1 << 30, (polys, n), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32)
+    rab = torch.empty((polys, 2 * n - 1), dtype=torch.int32, device="cuda")
+    plans = [ctx.plan(primes[start + j], n, polys) for j in range(count)]
+
+    def rns():
+        for pl in plans:
+            pl.multiply(ra, rb, out=rab, batch=polys)
+    if plans:
+        rns()
+        sync()
+        pl_p = primes[start + count - 1]                  # rab holds the last limb's products
+        for x in (1, pl_p - 1, 0x2545F491):
+            if not torch.equal(_eval_rows_t(torch, ra, x, pl_p) * _eval_rows_t(torch, rb, x, pl_p) % pl_p, _eval_rows_t(torch, rab, x, pl_p)):
+                failed.append("rns identity")
+                break
+        if rank == 0:
+            r = polys - 1
+            if not np.array_equal(rab[r].cpu().numpy().view(np.uint32),
+                                  orc.poly_multiply(ra[r].cpu().numpy().view(np.uint32), rb[r].cpu().numpy().view(np.uint32), pl_p)):
+                failed.append("rns oracle")
+    t = timed(rns, 3)
+    out["rns_32x256_n2p16_ms"] = 1e3 * t
+    out["rns_products_per_s"] = limbs * polys / t
+    out["rns_GBps"] = limbs * polys * (16 * n - 4) / t / 1e9
+    out["rns_limbs_per_rank"] = -(-limbs // world)
+    for pl in plans:
+        pl.close()
+    del ra, rb, rab
+
+    # (c) one transform of 2^26 points, forward + inverse
+    lgL, p = 26, 469762049
+    L = 1 << lgL
+    w = pow(3, (p - 1) // L, p)
+    if world == 1:
+        plan = ctx.plan(p, L // 2, 1)
+        gen.manual_seed(26)
+        x = torch.randint(0, p, (L,), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32)
+        y = x.clone()
+        plan.forward(y, 1)
+        sync()
+        k = 0x2B3C5D7 % L
+        if int(y[k].item()) != _eval_point_t(torch, x, pow(w, k, p), p):
+            failed.append("ntt point")
+        plan.inverse(y, 1)
+        sync()
+        if not torch.equal(y, x):
+            failed.append("ntt round trip")
+        t = timed(lambda: (plan.forward(y, 1), plan.inverse(y, 1)), 3)
+        out["ntt2p26_fwd_inv_ms"] = 1e3 * t
+        out["ntt2p26_GBps"] = 16 * L / t / 1e9
+        out["ntt2p26_sent_bytes_per_rank"] = 0
+        plan.close()
+    elif world & (world - 1) == 0 and world <= 64:
+        S = L // world
+        dp = ntt_amd.DistPlan(ctx, p, lgL, world, rank)
+        dx = shard.DistExchange(group, ctx, dp, on_device_exchange=on_device)
+        gen.manual_seed(26 + rank)
+        x = torch.randint(0, p, (S,), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32)
+        X = dx.forward(x).clone()                         # X[k2] = transform point rank + world * k2
+        back = dx.inverse(X)
+        sync()
+        if not torch.equal(back, x):
+            failed.append("ntt round trip")
+        if rank == 0:                                     # one output point by direct evaluation over every rank's block
+            blocks = []
+            for r in range(world):
+                gen.manual_seed(26 + r)
+                blocks.append(torch.randint(0, p, (S,), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32))
+            k2 = 0x2B3C5D7 % S
+            if int(X[k2].item()) != _eval_point_t(torch, torch.cat(blocks), pow(w, world * k2, p), p):
+                failed.append("ntt point")
+            del blocks
+        t = timed(lambda: dx.inverse(dx.forward(x)), 3)
+        out["ntt2p26_fwd_inv_ms"] = 1e3 * t
+        out["ntt2p26_GBps"] = 16 * L / t / 1e9
+        out["ntt2p26_sent_bytes_per_rank"] = 4 * (world - 1) * (S // world) * 4       # two all-to-alls each way
+        dp.close()
+    else:
+        out["ntt2p26_skipped"] = "needs a power-of-two number of ranks"
+    ctx.close()
+    nfailed = group.sum_over_ranks(float(len(failed)))
+    out["checks"] = "ok" if nfailed == 0 else "FAILED on some rank: " + ", ".join(failed)
     return out
 
 
@@ -195,6 +411,11 @@ def parse_args(argv=None):
     ap.add_argument("--sustained-seconds", type=float, default=2.5,
                     help="length of the untimed-by-the-driver loop behind `roofline.sustained` (0 = skip)")
     ap.add_argument("--no-one-lane", action="store_true", help="skip the one-lane per-kernel table")
+    ap.add_argument("--no-also", action="store_true", help="skip the `also` block (CRT, RNS and 2^26 workloads behind the headline loop)")
+    ap.add_argument("--also-timeout", type=float, default=90.0, help="watchdog of the `also` block, seconds")
+    ap.add_argument("--with-ref", action="store_true",
+                    help="cpu_baseline also times oracle/_ref (the reference's main-baseline.cc compiled in the build container); "
+                         "off by default: the default run executes nothing built from /root/reference")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch, rendezvous, barrier and the max-over-ranks only: no GPU work, value = null "
                          "(exercises the N-rank start-up on a box without a GPU)")
@@ -362,7 +583,32 @@ def main(argv=None):
         plan1.close()
         ctx1.close()
 
+    # the other sharded workloads, behind the headline loop; a watchdog keeps a hung exchange from taking the line along
+    also = None
+    if not args.no_also and not args.no_kernel_timing:
+        import threading
+        headline = {"value": world * B * args.steps / elapsed, "n_gpus": world, "ms_per_step": 1e3 * elapsed / args.steps}
+
+        def give_up():
+            if rank == 0:
+                print(json.dumps({"metric": "poly-mults/sec at n=2^17 (32-bit p)", "unit": "poly-mults/s", "steps": args.steps,
+                                  "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                                  "dtype": "u32", "data": "synthetic", **headline,
+                                  "also": {"error": f"the also block did not finish within {args.also_timeout} s; headline only"}}),
+                      flush=True)
+            os._exit(0)
+        dog = threading.Timer(args.also_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            also = also_block(args, group, rank, world, local_rank)
+        except Exception as e:                       # the headline measurement stands; say what happened
+            also = {"error": f"{type(e).__name__}: {e}"[:300]}
+        dog.cancel()
+
     rc = 0
+    if also is not None and (str(also.get("checks", "ok")) != "ok"):
+        rc = 1
     if rank == 0 and args.no_kernel_timing:         # sweeps (tools/): the rate only
         print(json.dumps({"value": world * B * args.steps / elapsed, "n_gpus": world,
                           "ms_per_step": 1e3 * elapsed / args.steps, "chunk": args.chunk}), flush=True)
@@ -433,11 +679,31 @@ def main(argv=None):
                          "traffic_detail": traffic_info,
                          "pipeline_achieved": value / world * alg_bytes / 1e9,
                          "pipeline_frac": value / world * alg_bytes / 1e9 / HBM_PEAK_GBPS,
+                         # what actually binds: integer VALU issue.  Scalars, so that they
+                         # survive next to `frac`: the pipeline's VALU lane-op rate against the rate the butterfly's
+                         # instruction mix reaches beside this much memory traffic (COUPLED_MIX_PEAK_TLANEOPS,
+                         # profiles/ubench_clock_r02.txt), against the same mix alone, and against the issue-cycle model
+                         "binding": "valu-int" if valu else "unknown (no VALU model for this shape)",
+                         "valu_frac_of_coupled_peak": valu and valu["achieved"] / COUPLED_MIX_PEAK_TLANEOPS,
+                         "valu_frac_of_mix_peak": valu and valu["frac_of_measured_mix_peak"],
+                         "valu_frac_of_issue_model": valu and valu["frac"],
+                         "valu_coupled_peak_TlaneOps": COUPLED_MIX_PEAK_TLANEOPS,
+                         "valu_achieved_TlaneOps": valu and valu["achieved"],
+                         "sustained_value": sustained and sustained["value"],
+                         "one_lane_col_fwd_us": one_lane and one_lane.get("col_fwd", {}).get("us_per_product"),
+                         "one_lane_row_mul_us": one_lane and one_lane.get("row_mul", {}).get("us_per_product"),
+                         "one_lane_col_inv_us": one_lane and one_lane.get("col_inv", {}).get("us_per_product"),
+                         # the dominant kernel alone on one stream lane (uncontended): `frac` above is computed from
+                         # its duration in the timed region, where the other lane's row kernel runs beside it
+                         "frac_one_lane": one_lane and name in one_lane and
+                                          alg_bytes / (one_lane[name]["us_per_product"] * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                          "kernel_ms_per_step_untimed": {k: v[0] / 2 for k, v in warm_ktimes.items()},
                          "kernels_one_lane": one_lane, "valu": valu, "sustained": sustained},
         }
+        if also is not None:
+            out["also"] = also
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, p, args.cpu_seconds, gpu_row0)
+            out["cpu_baseline"] = cpu_baseline(n, p, args.cpu_seconds, gpu_row0, args.with_ref)
         print(json.dumps(out), flush=True)
 
     barrier()                       # rank 0 ran the one-lane table meanwhile: every rank leaves the group together

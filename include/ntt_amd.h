@@ -42,7 +42,7 @@ typedef enum {
  * quotients. */
 typedef enum { NTT_MODMUL_MONTGOMERY = 0, NTT_MODMUL_BARRETT = 1 } ntt_modmul_kind;
 
-typedef struct ntt_ctx ntt_ctx;     /* one GPU + one stream; thread-safe per handle */
+typedef struct ntt_ctx ntt_ctx;     /* one GPU + one stream (or one slot per GPU, ntt_ctx_create); thread-safe per handle */
 typedef struct ntt_plan ntt_plan;   /* (p, n, L, batch capacity, twiddle tables, work buffers) */
 
 /* ---- 1. the reference's own entry point --------------------------------------------------- */
@@ -59,10 +59,36 @@ void poly_multiply(int *a, int *b, int *ab, int n, int p);
 
 /* ---- 2. handle API ------------------------------------------------------------------------ */
 
-/* Create a context on the given HIP device(s).  One process drives one GPU (multi-GPU runs are
- * one process per GPU); ndev must be 1.  No reference counterpart (the reference's CUDA files
- * use the implicit device, e.g. main-montgomery-GPU.cu:383). */
+/* Create a context on the given HIP device(s).
+ * ndev == 1: one GPU + one stream; every entry point below takes such a context (the reference's CUDA files use the
+ * implicit device, e.g. main-montgomery-GPU.cu:383).
+ * ndev > 1: a MULTI-DEVICE context, the in-library form of the reference's distributed program main-mpi.cc:642-819
+ * for one process that drives the GPUs of a node over HIP peer-to-peer (xGMI): one "slot" per entry of device_ids
+ * (an id may repeat: {0, 0, 0, 0} rehearses four slots on a one-GPU box); peer access is enabled between every pair
+ * of distinct devices.  On such a context
+ *   - ntt_plan_create / ntt_negacyclic_plan_create make one plan per slot; ntt_poly_multiply_batched,
+ *     ntt_negacyclic_multiply_batched, ntt_forward and ntt_inverse shard their batch rows over the slots:
+ *     slot s takes rows [s * ceil(batch / ndev), ...), the reference's rule for primes (main-mpi.cc:657-660)
+ *     applied to independent products -- no exchange.  Arrays may be host arrays (each slot stages its rows) or
+ *     device arrays that every slot can reach (its own device, or any device of the context with peer access);
+ *   - ntt_crt_multiply puts prime k on slot k / ceil(4 / ndev) (main-mpi.cc:657-660, :770), then ONE exchange:
+ *     every slot receives coefficient slice h of all four residue polynomials (peer copies), merges its slice on
+ *     its own GPU and writes it to ab -- instead of the reference's gather to rank 0 and merge there
+ *     (main-mpi.cc:772-796); ntt_crt_multiply_batched with batch > 1 shards the products by rows instead;
+ *   - ntt_dist_plan_create (world = ndev) + ntt_dist_forward / ntt_dist_inverse run ONE transform split over the
+ *     slots with both exchanges inside the library (below);
+ *   - calls return when the result is complete, except ntt_dist_forward / ntt_dist_inverse and calls whose arrays
+ *     are all device arrays (queued; ntt_ctx_synchronize waits for every slot);
+ *   - everything else (streams, kernel timing, 64-bit plans, the CRT halves, streamed and no-alloc products) is per
+ *     slot: ntt_ctx_device(ctx, slot, &slot_ctx, &device) hands out the slot's single-device context, owned by ctx. */
 int ntt_ctx_create(const int *device_ids, int ndev, ntt_ctx **out_ctx);
+int ntt_ctx_device_count(const ntt_ctx *ctx);
+/* The sharding rule every multi-device call uses, as a function: units [*start, *start + *count) of `total_units` belong
+ * to slot (or rank) `rank` of `world` -- ceil(total / world) units each, the last ones fewer or none.  It is the
+ * reference's rule for its four primes, mods_per_process = ceil(4 / size), start = rank * mods_per_process,
+ * end = min(start + mods_per_process, 4) (main-mpi.cc:657-660), for any number of units.  Pure host arithmetic. */
+int ntt_partition(long total_units, int world, int rank, long *start, long *count);
+int ntt_ctx_device(ntt_ctx *ctx, int slot, ntt_ctx **out_slot_ctx, int *out_device);
 /* Destroy every plan made from a context BEFORE the context: a plan handle points into its context. */
 int ntt_ctx_destroy(ntt_ctx *ctx);
 /* Use an existing hipStream_t (passed as void*) for all work of this context; NULL restores the
@@ -220,6 +246,23 @@ int ntt_dist_plan_destroy(ntt_dist_plan *plan);
 int ntt_dist_colpass(ntt_dist_plan *plan, uint32_t *data, int inverse);
 int ntt_dist_local(ntt_dist_plan *plan, uint32_t *row, int inverse);
 int ntt_dist_local_length(const ntt_dist_plan *plan);
+/* The same transform with the exchanges INSIDE the library, for a plan made from a multi-device context
+ * (ntt_dist_plan_create(ctx, p, lgL, world = ntt_ctx_device_count(ctx), rank ignored, ...); world 2, 4, 8 or 16).
+ * in[r], out[r] (r < world) are device arrays of S = L / world u32 on the device of slot r, in[r] != out[r]:
+ *   ntt_dist_forward   in[r] = x[r*S .. (r+1)*S)            ->  out[r][k2] = X[r + world*k2]
+ *   ntt_dist_inverse   in[r][k2] = X[r + world*k2]          ->  out[r] = x[r*S .. (r+1)*S), scaled by L^-1
+ * in[] is not modified.  The column kernel of slot h loads the world points of each of its columns from the arrays
+ * of the slots that hold them and stores row k1 into slot k1's array: both all-to-alls of the decomposition above
+ * are peer loads / stores over xGMI inside one kernel per device (transport "p2p", the default with peer access).
+ * NTT_AMD_DIST_TRANSPORT (read at plan creation) = "copyin": the first exchange is hipMemcpyPeerAsync per peer slice
+ * into a local array, cut into NTT_AMD_DIST_CHUNKS (4) column chunks so that the copies of chunk c + 1 run beside the
+ * kernel of chunk c, the second stays peer stores; = "copy": both exchanges are peer copies (the default without
+ * peer access).  Queued on the slots' streams: ntt_ctx_synchronize(ctx) waits.  The arrays must be complete when the
+ * call is made (it orders itself only against earlier calls on the same plan).
+ * ntt_dist_plan_transport reports the transport in use (0 p2p, 1 copyin, 2 copy; -1 for a single-device plan). */
+int ntt_dist_forward(ntt_dist_plan *plan, const uint32_t *const *in, uint32_t *const *out);
+int ntt_dist_inverse(ntt_dist_plan *plan, const uint32_t *const *in, uint32_t *const *out);
+int ntt_dist_plan_transport(const ntt_dist_plan *plan, int *transport, int *chunks);
 
 /* Per-kernel timing (HIP events on the context's stream) for bench.py's roofline block.
  * With timing enabled every kernel launch is bracketed by events; ntt_ctx_kernel_time returns

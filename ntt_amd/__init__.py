@@ -43,6 +43,7 @@ EXPORTED_SYMBOLS = (
     "ntt_plan64_create", "ntt_plan64_destroy", "ntt_plan64_length", "ntt_poly_multiply64_batched",
     "ntt_crt_residue_multiply", "ntt_crt_merge", "ntt_dist_plan_create", "ntt_dist_plan_destroy",
     "ntt_dist_colpass", "ntt_dist_local", "ntt_dist_local_length",
+    "ntt_ctx_device_count", "ntt_ctx_device", "ntt_partition", "ntt_dist_forward", "ntt_dist_inverse", "ntt_dist_plan_transport",
     "ntt_ctx_enable_kernel_timing", "ntt_ctx_kernel_timing_select", "ntt_ctx_kernel_time", "ntt_last_error", "ntt_read_case",
     "ntt_check_case", "ntt_write_case", "ntt_poly_multiply_stream", "ntt_host_alloc", "ntt_host_free",
     "ntt_pack_case", "ntt_read_case_bin", "ntt_check_case_bin", "ntt_write_case_bin",
@@ -95,6 +96,12 @@ def _load():
     lib.ntt_dist_colpass.argtypes = [vp, vp, i32]
     lib.ntt_dist_local.argtypes = [vp, vp, i32]
     lib.ntt_dist_local_length.argtypes = [vp]
+    lib.ntt_ctx_device_count.argtypes = [vp]
+    lib.ntt_partition.argtypes = [C.c_long, i32, i32, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    lib.ntt_ctx_device.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32)]
+    lib.ntt_dist_forward.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.ntt_dist_inverse.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.ntt_dist_plan_transport.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.ntt_ctx_enable_kernel_timing.argtypes = [vp, i32]
     lib.ntt_ctx_kernel_timing_select.argtypes = [vp, i32]
     lib.ntt_ctx_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
@@ -141,15 +148,36 @@ def _ptr(x, dtype, need=0):
 
 
 class Context:
-    """One GPU + one stream (``ntt_ctx``)."""
+    """One GPU + one stream (``ntt_ctx``), or -- ``Context(devices=[0, 1, 2, 3])`` -- a multi-device context with one
+    slot per listed device (ids may repeat: a one-GPU box rehearses ``[0, 0, 0, 0]``), whose plans, products and
+    transforms are sharded over the slots inside the library (``include/ntt_amd.h``, ``ntt_ctx_create``)."""
 
-    def __init__(self, device=0):
-        dev = C.c_int(device)
+    def __init__(self, device=0, devices=None):
         h = C.c_void_p()
-        _check(_lib.ntt_ctx_create(C.byref(dev), 1, C.byref(h)))
+        if devices is None:
+            dev = C.c_int(device)
+            _check(_lib.ntt_ctx_create(C.byref(dev), 1, C.byref(h)))
+            self.devices = [device]
+        else:
+            self.devices = [int(d) for d in devices]
+            arr = (C.c_int * len(self.devices))(*self.devices)
+            _check(_lib.ntt_ctx_create(arr, len(self.devices), C.byref(h)))
+            device = self.devices[0]
         self._h = h
         self.device = device
         self._plans = weakref.WeakSet()      # live plans: a plan's destroy call dereferences its context
+
+    @property
+    def device_count(self):
+        return _lib.ntt_ctx_device_count(self._h)
+
+    def slot(self, index):
+        """The single-device context of slot `index` (owned by this context; do not close it)."""
+        h, dev = C.c_void_p(), C.c_int()
+        _check(_lib.ntt_ctx_device(self._h, int(index), C.byref(h), C.byref(dev)))
+        view = Context.__new__(Context)
+        view._h, view.device, view.devices, view._plans, view._borrowed = h, dev.value, [dev.value], weakref.WeakSet(), self
+        return view
 
     def close(self):
         """Destroys the context after closing every plan made from it that is still open (a plan handle
@@ -157,7 +185,8 @@ class Context:
         if self._h:
             for pl in list(self._plans):
                 pl.close()
-            _lib.ntt_ctx_destroy(self._h)
+            if getattr(self, "_borrowed", None) is None:      # a slot view does not own its handle
+                _lib.ntt_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -432,6 +461,27 @@ class DistPlan:
         _check(_lib.ntt_dist_local(self._h, _ptr(row, np.uint32, self.local_length), 1 if inverse else 0))
         return row
 
+    @property
+    def transport(self):
+        """(name, column chunks) of the in-library exchange of a multi-device plan; (None, 0) for one rank's plan."""
+        t, c = C.c_int(), C.c_int()
+        _check(_lib.ntt_dist_plan_transport(self._h, C.byref(t), C.byref(c)))
+        return ({0: "p2p", 1: "copyin", 2: "copy"}.get(t.value), c.value)
+
+    def _blocks(self, arrays):
+        if len(arrays) != self.world:
+            raise ValueError(f"expected {self.world} blocks, one per slot")
+        return (C.c_void_p * self.world)(*[_ptr(x, np.uint32, self.local_length).value for x in arrays])
+
+    def forward(self, blocks_in, blocks_out):
+        """Multi-device plan: blocks_in[r] = x[r*S:(r+1)*S] on slot r -> blocks_out[r][k2] = X[r + world*k2] (queued)."""
+        _check(_lib.ntt_dist_forward(self._h, self._blocks(blocks_in), self._blocks(blocks_out)))
+        return blocks_out
+
+    def inverse(self, blocks_in, blocks_out):
+        _check(_lib.ntt_dist_inverse(self._h, self._blocks(blocks_in), self._blocks(blocks_out)))
+        return blocks_out
+
 
 class _PinnedOwner:
     def __init__(self, ptr):
@@ -487,6 +537,13 @@ def write_case_bin(directory, case_id, ab, p):
     assert ab.dtype in (np.uint32, np.uint64)
     n = (ab.size + 1) // 2
     _check(_lib.ntt_write_case_bin(str(directory).encode(), case_id, ab.ctypes.data, n, int(p), ab.dtype.itemsize))
+
+
+def partition(total_units, world, rank):
+    """(start, count) of slot `rank`'s units: the library's own sharding rule (``ntt_partition``, main-mpi.cc:657-660)."""
+    st, cnt = C.c_long(), C.c_long()
+    _check(_lib.ntt_partition(int(total_units), int(world), int(rank), C.byref(st), C.byref(cnt)))
+    return st.value, cnt.value
 
 
 def crt_prime(index):

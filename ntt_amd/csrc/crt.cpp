@@ -103,6 +103,7 @@ extern "C" int ntt_crt_multiply_batched(ntt_ctx *ctx, const uint64_t *a, const u
 try {
     if (!ctx || !a || !b || !ab) return fail(NTT_ERR_INVALID, "ntt_crt_multiply: null argument");
     if (n <= 0 || batch <= 0) return fail(NTT_ERR_INVALID, "ntt_crt_multiply: n and batch must be positive");
+    if (ctx->is_group()) return group_crt_multiply(ctx, a, b, ab, n, p64, batch);    // prime per slot + one exchange (multidev.cpp)
     if ((uint64_t)batch * (uint64_t)n > (1ull << 28)) return fail(NTT_ERR_UNSUPPORTED, "ntt_crt_multiply_batched: batch * n above 2^28");
     if ((p64 & 1) == 0 || p64 < 3 || p64 >= (1ULL << 62))
         return fail(NTT_ERR_UNSUPPORTED, "ntt_crt_multiply: p64 must be odd and below 2^62");
@@ -329,6 +330,7 @@ NTT_CATCH_STATUS
 static int crt_check(ntt_ctx *ctx, int n, uint64_t p64, bool need_p64)
 {
     if (!ctx) return fail(NTT_ERR_INVALID, "null context");
+    if (ctx->is_group()) return fail(NTT_ERR_UNSUPPORTED, "the halves of the CRT path run on one slot: use ntt_ctx_device(ctx, slot)");
     if (n <= 0) return fail(NTT_ERR_INVALID, "n must be positive");
     if (n > (1 << 22)) return fail(NTT_ERR_UNSUPPORTED, "n too large for the 2^23-adic prime 998244353");
     if (need_p64 && ((p64 & 1) == 0 || p64 < 3 || p64 >= (1ULL << 62)))

@@ -353,6 +353,7 @@ NTT_CATCH_STATUS
 static int plan64_create(ntt_ctx *ctx, uint64_t p64, int n, int batch, bool negacyclic, ntt_plan64 **out)
 {
     if (!ctx || !out) return fail(NTT_ERR_INVALID, "ntt_plan64_create: null argument");
+    if (ctx->is_group()) return fail(NTT_ERR_UNSUPPORTED, "ntt_plan64_create: 64-bit plans live on one slot: use ntt_ctx_device(ctx, slot)");
     if (n <= 0 || batch <= 0) return fail(NTT_ERR_INVALID, "ntt_plan64_create: n and batch must be positive");
     if (n > (1 << 23)) return fail(NTT_ERR_UNSUPPORTED, "ntt_plan64_create: n above 2^23");
     if (p64 < 3 || p64 >= (1ULL << 62) || !is_prime64(p64))

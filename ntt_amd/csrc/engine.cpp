@@ -620,29 +620,31 @@ static void permute_pass(ntt_plan *pl, const uint32_t *src, uint32_t *dst, bool 
     cx->end();
 }
 
-// data: DEVICE pointer, [batch][L], transformed in place (natural order in and out).
+// src, data: DEVICE pointers, [batch][L]; natural order in and out.  src == data transforms in place; otherwise src
+// is only read (the first pass of either direction takes it as its input) and the result lands in data.
 template <class MM>
-static int transform_device(ntt_plan *pl, uint32_t *data, int batch, bool inverse)
+static int transform_device(ntt_plan *pl, const uint32_t *src, uint32_t *data, int batch, bool inverse)
 {
     const uint32_t L = pl->L;
     pl->ctx->cur = pl->ctx->stream;
     if (pl->logL <= kRowLog) {
-        small_pass<MM>(pl, inverse ? 2 : 1, data, nullptr, data, L, L, L, L, (unsigned)batch);
+        small_pass<MM>(pl, inverse ? 2 : 1, src, nullptr, data, L, L, L, L, (unsigned)batch);
         return NTT_OK;
     }
     uint32_t *w0 = static_cast<uint32_t *>(pl->work0.ptr);
     const int m = pl->nlevels;
     for (int c0 = 0; c0 < batch; c0 += pl->chunk) {
         const unsigned cb = (unsigned)std::min(pl->chunk, batch - c0);
+        const uint32_t *s = src + (size_t)c0 * L;
         uint32_t *d = data + (size_t)c0 * L;
         if (!inverse) {
             for (int j = 0; j < m; ++j)
-                col_pass<MM>(pl, j, false, false, d, nullptr, d, nullptr, L, L, L, L, pl->tw_fwd[j], false,
+                col_pass<MM>(pl, j, false, false, j == 0 ? s : d, nullptr, d, nullptr, L, L, L, L, pl->tw_fwd[j], false,
                              {}, false, cb, 1);
             row_pass<MM>(pl, 1, d, nullptr, w0, cb * (L >> kRowLog));
             permute_pass(pl, w0, d, true, cb);
         } else {
-            permute_pass(pl, d, w0, false, cb);
+            permute_pass(pl, s, w0, false, cb);
             row_pass<MM>(pl, 2, w0, nullptr, w0, cb * (L >> kRowLog));
             for (int j = m - 1; j >= 0; --j)
                 col_pass<MM>(pl, j, true, false, w0, nullptr, j == 0 ? d : w0, nullptr, L, L, L, L,
@@ -651,6 +653,20 @@ static int transform_device(ntt_plan *pl, uint32_t *data, int batch, bool invers
         }
     }
     return NTT_OK;
+}
+
+// One transform of the plan's length from src to dst (DEVICE pointers on the plan's GPU, src == dst allowed), queued
+// on the context's stream: the local S-point transforms of the in-library distributed transform (multidev.cpp).
+int transform_device_any(ntt_plan *pl, const uint32_t *src, uint32_t *dst, bool inverse)
+{
+    ntt_ctx *cx = pl->ctx;
+    std::lock_guard<std::mutex> lk(cx->mu);
+    HIP_TRY(hipSetDevice(cx->device));
+    const int rc = pl->kind == NTT_MODMUL_MONTGOMERY ? transform_device<Mont32>(pl, src, dst, 1, inverse)
+                                                     : transform_device<Barrett32>(pl, src, dst, 1, inverse);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return take_launch_error();
 }
 
 }  // namespace ntt
@@ -729,7 +745,8 @@ int ntt_ctx_create(const int *device_ids, int ndev, ntt_ctx **out_ctx)
 try {
     if (!out_ctx) return fail(NTT_ERR_INVALID, "ntt_ctx_create: out_ctx is null");
     *out_ctx = nullptr;
-    if (ndev != 1) return fail(NTT_ERR_UNSUPPORTED, "ntt_ctx_create: one process drives one GPU (ndev must be 1)");
+    if (ndev < 1) return fail(NTT_ERR_INVALID, "ntt_ctx_create: ndev must be at least 1");
+    if (ndev > 1) return group_ctx_create(device_ids, ndev, out_ctx);        // one slot per entry of device_ids (multidev.cpp)
     int dev = device_ids ? device_ids[0] : 0, count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     if (dev < 0 || dev >= count) return fail(NTT_ERR_INVALID, "ntt_ctx_create: no such device");
@@ -783,6 +800,7 @@ NTT_CATCH_STATUS
 int ntt_ctx_set_stream(ntt_ctx *ctx, void *hip_stream)
 try {
     if (!ctx) return fail(NTT_ERR_INVALID, "null context");
+    if (ctx->is_group()) return fail(NTT_ERR_UNSUPPORTED, "ntt_ctx_set_stream: a multi-device context has one stream per slot: set it on ntt_ctx_device(ctx, slot)");
     std::lock_guard<std::mutex> lk(ctx->mu);
     // (void*)1 = hipStreamLegacy names the null stream; the runtime's own handling of that handle in
     // hipEventRecord / hipStreamWaitEvent faults (ROCm 7.0 runtime bundled with PyTorch), its handle 0 does not
@@ -797,6 +815,7 @@ void *ntt_ctx_stream(ntt_ctx *ctx) { return ctx ? static_cast<void *>(ctx->strea
 int ntt_ctx_synchronize(ntt_ctx *ctx)
 try {
     if (!ctx) return fail(NTT_ERR_INVALID, "null context");
+    if (ctx->is_group()) return group_ctx_synchronize(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return NTT_OK;
@@ -806,6 +825,7 @@ NTT_CATCH_STATUS
 int ntt_ctx_enable_kernel_timing(ntt_ctx *ctx, int enable)
 try {
     if (!ctx) return fail(NTT_ERR_INVALID, "null context");
+    if (ctx->is_group()) return fail(NTT_ERR_UNSUPPORTED, "kernel timing is per slot: use ntt_ctx_device(ctx, slot)");
     std::lock_guard<std::mutex> lk(ctx->mu);
     int rc = ctx->fold();
     ctx->timing = enable != 0;
@@ -817,6 +837,7 @@ NTT_CATCH_STATUS
 int ntt_ctx_kernel_timing_select(ntt_ctx *ctx, int index)
 try {
     if (!ctx || index < -1 || index >= K_COUNT) return fail(NTT_ERR_INVALID, "ntt_ctx_kernel_timing_select: bad index");
+    if (ctx->is_group()) return fail(NTT_ERR_UNSUPPORTED, "kernel timing is per slot: use ntt_ctx_device(ctx, slot)");
     std::lock_guard<std::mutex> lk(ctx->mu);
     int rc = ctx->fold();
     ctx->timing_only = index;
@@ -827,6 +848,7 @@ NTT_CATCH_STATUS
 int ntt_ctx_kernel_time(ntt_ctx *ctx, int index, const char **name, double *total_ms, long *launches)
 try {
     if (!ctx || index < 0 || index >= K_COUNT) return fail(NTT_ERR_INVALID, "ntt_ctx_kernel_time: bad index");
+    if (ctx->is_group()) return fail(NTT_ERR_UNSUPPORTED, "kernel timing is per slot: use ntt_ctx_device(ctx, slot)");
     std::lock_guard<std::mutex> lk(ctx->mu);
     int rc = ctx->fold();
     if (rc) return rc;
@@ -840,6 +862,7 @@ NTT_CATCH_STATUS
 int ntt_plan_destroy(ntt_plan *pl)
 try {
     if (!pl) return NTT_OK;
+    if (!pl->shard.empty()) return group_plan_destroy(pl);
     (void)hipSetDevice(pl->ctx->device);
     (void)hipStreamSynchronize(pl->ctx->stream);
     for (void *d : pl->owned) (void)hipFree(d);
@@ -854,6 +877,7 @@ NTT_CATCH_STATUS
 int ntt_ctx_destroy(ntt_ctx *ctx)
 try {
     if (!ctx) return NTT_OK;
+    if (ctx->is_group()) return group_ctx_destroy(ctx);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->plan_cache) ntt_plan_destroy(kv.second);
@@ -904,6 +928,7 @@ static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_ki
     if (p >= (1u << 31) || p < 3 || !h_is_prime(p))
         return fail(NTT_ERR_UNSUPPORTED, "ntt_plan_create: p must be an odd prime below 2^31");
     if (n > (1 << 25)) return fail(NTT_ERR_UNSUPPORTED, "ntt_plan_create: n too large (transform length is capped at 2^26)");
+    if (ctx->is_group() && force_logL == 0) return group_plan_create(ctx, p, n, batch, modmul_kind, negacyclic, out_plan);
     int logL = 1;
     while ((1u << logL) < 2u * (uint32_t)n) ++logL;
     if (negacyclic) --logL;                               // x^n + 1: transform length n, 2n-th root psi
@@ -1039,6 +1064,11 @@ static int multiply_entry(ntt_plan *pl, const uint32_t *a, const uint32_t *b, ui
     if (pl->negacyclic != negacyclic)
         return fail(NTT_ERR_INVALID, negacyclic ? "ntt_negacyclic_multiply_batched: the plan is not a negacyclic plan"
                                                 : "ntt_poly_multiply_batched: negacyclic plans multiply through ntt_negacyclic_multiply_batched");
+    if (!pl->shard.empty()) {                              // plan of a multi-device context: rows sharded over the slots
+        const size_t row_len = negacyclic ? (size_t)pl->n : 2 * (size_t)pl->n - 1;
+        if (ab_stride < row_len) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched: output row stride below the row length");
+        return group_multiply(pl, a, b, ab, ab_stride, batch, negacyclic);
+    }
     if (batch <= 0) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched: batch must be positive");
     if (batch > pl->batch) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched: batch exceeds the plan's capacity");
     const size_t n = (size_t)pl->n, out_len = negacyclic ? n : 2 * n - 1;
@@ -1089,6 +1119,7 @@ int ntt_poly_multiply_batched_noalloc(ntt_plan *pl, const uint32_t *a, const uin
 try {
     if (!pl || !a || !b || !ab) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched_noalloc: null argument");
     if (pl->negacyclic) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched_noalloc: not for negacyclic plans");
+    if (!pl->shard.empty()) return fail(NTT_ERR_UNSUPPORTED, "ntt_poly_multiply_batched_noalloc: not for plans of a multi-device context");
     if (batch <= 0) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched_noalloc: batch must be positive");
     if (batch > 65535) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched_noalloc: batch above 65535");
     const size_t n = (size_t)pl->n, out_len = 2 * n - 1;
@@ -1139,6 +1170,7 @@ NTT_CATCH_STATUS
 static int transform_entry(ntt_plan *pl, uint32_t *data, int batch, bool inverse)
 {
     if (!pl || !data) return fail(NTT_ERR_INVALID, "ntt_forward/inverse: null argument");
+    if (!pl->shard.empty()) return group_transform(pl, data, batch, inverse);
     if (batch <= 0) return fail(NTT_ERR_INVALID, "ntt_forward/inverse: batch must be positive");
     if (batch > pl->batch) return fail(NTT_ERR_INVALID, "ntt_forward/inverse: batch exceeds the plan's capacity");
     ntt_ctx *cx = pl->ctx;
@@ -1153,8 +1185,8 @@ static int transform_entry(ntt_plan *pl, uint32_t *data, int batch, bool inverse
         HIP_TRY(hipMemcpyAsync(cx->stage_a.ptr, data, bytes, hipMemcpyHostToDevice, cx->stream));
         d = static_cast<uint32_t *>(cx->stage_a.ptr);
     }
-    int rc = pl->kind == NTT_MODMUL_MONTGOMERY ? transform_device<Mont32>(pl, d, batch, inverse)
-                                               : transform_device<Barrett32>(pl, d, batch, inverse);
+    int rc = pl->kind == NTT_MODMUL_MONTGOMERY ? transform_device<Mont32>(pl, d, d, batch, inverse)
+                                               : transform_device<Barrett32>(pl, d, d, batch, inverse);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     if (int lrc_ = ntt::take_launch_error()) return lrc_;
@@ -1239,6 +1271,7 @@ extern "C" {
 int ntt_dist_plan_destroy(ntt_dist_plan *dp)
 try {
     if (!dp) return NTT_OK;
+    if (!dp->part.empty() || !dp->gslot.empty()) group_dist_plan_release(dp);
     if (dp->local) ntt_plan_destroy(dp->local);
     if (dp->colp) ntt_plan_destroy(dp->colp);
     delete dp;
@@ -1251,6 +1284,7 @@ int ntt_dist_plan_create(ntt_ctx *ctx, uint32_t p, int lgL, int world, int rank,
 try {
     if (!ctx || !out) return fail(NTT_ERR_INVALID, "ntt_dist_plan_create: null argument");
     *out = nullptr;
+    if (ctx->is_group()) return group_dist_plan_create(ctx, p, lgL, world, modmul_kind, out);    // every rank's pieces; `rank` is not used
     if (world < 2 || world > 64 || (world & (world - 1)) || rank < 0 || rank >= world)
         return fail(NTT_ERR_INVALID, "ntt_dist_plan_create: world must be a power of two in 2..64, 0 <= rank < world");
     int lgG = 0;
@@ -1298,6 +1332,7 @@ NTT_CATCH_STATUS
 int ntt_dist_colpass(ntt_dist_plan *dp, uint32_t *data, int inverse)
 try {
     if (!dp || !data) return fail(NTT_ERR_INVALID, "ntt_dist_colpass: null argument");
+    if (!dp->part.empty()) return fail(NTT_ERR_INVALID, "ntt_dist_colpass: plan of a multi-device context (its exchanges run inside ntt_dist_forward / ntt_dist_inverse)");
     ntt_ctx *cx = dp->ctx;
     std::lock_guard<std::mutex> lk(cx->mu);
     HIP_TRY(hipSetDevice(cx->device));
@@ -1321,6 +1356,7 @@ NTT_CATCH_STATUS
 int ntt_dist_local(ntt_dist_plan *dp, uint32_t *row, int inverse)
 try {
     if (!dp) return fail(NTT_ERR_INVALID, "ntt_dist_local: null argument");
+    if (!dp->part.empty()) return fail(NTT_ERR_INVALID, "ntt_dist_local: plan of a multi-device context (use ntt_dist_forward / ntt_dist_inverse)");
     return inverse ? ntt_inverse(dp->local, row, 1) : ntt_forward(dp->local, row, 1);
 }
 NTT_CATCH_STATUS

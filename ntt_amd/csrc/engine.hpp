@@ -1,5 +1,6 @@
 // engine.hpp -- host-side engine objects behind the C ABI (include/ntt_amd.h).
 #pragma once
+#include <algorithm>
 #include <array>
 #include <map>
 #include <memory>
@@ -12,6 +13,7 @@
 struct ntt_plan;
 struct ntt_plan64;
 struct ntt_ctx;
+struct ntt_dist_plan;
 
 namespace ntt {
 
@@ -66,6 +68,29 @@ struct WorkArea {
 // device-pointer entry used by the CRT path (caller holds ctx->mu); area == nullptr: the plan's buffers and lanes
 int multiply_device_any(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
                         size_t ab_stride, int batch, const WorkArea *area = nullptr);
+// one transform of the plan's length, src -> dst (device pointers on the plan's GPU; src == dst allowed), on the context's stream
+int transform_device_any(ntt_plan *pl, const uint32_t *src, uint32_t *dst, bool inverse);
+
+// ---- multi-device ("group") contexts: ntt_ctx_create with ndev > 1 (multidev.cpp) ----------------------------------
+// (start, count) of the contiguous block of `total` units owned by slot `rank` of `world`: ceil(total / world) units per
+// slot, the last slots may own fewer or none -- main-mpi.cc:657-660 (mods_per_process = ceil(4 / size)), generalised
+inline void partition(long total, int world, int rank, long *start, long *count)
+{
+    const long per = (total + world - 1) / world;
+    *start = std::min((long)rank * per, total);
+    *count = std::max(0L, std::min(per, total - *start));
+}
+struct GroupCrt;                          // per-slot exchange buffers of the prime-per-device CRT product
+int group_ctx_create(const int *device_ids, int ndev, ntt_ctx **out);
+int group_ctx_destroy(ntt_ctx *g);
+int group_ctx_synchronize(ntt_ctx *g);
+int group_plan_create(ntt_ctx *g, uint32_t p, int n, int batch, int kind, bool negacyclic, ntt_plan **out);
+int group_plan_destroy(ntt_plan *pl);
+int group_multiply(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab, size_t ab_stride, int batch, bool negacyclic);
+int group_transform(ntt_plan *pl, uint32_t *data, int batch, bool inverse);
+int group_crt_multiply(ntt_ctx *g, const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p64, int batch);
+int group_dist_plan_create(ntt_ctx *g, uint32_t p, int lgL, int world, int kind, ntt_dist_plan **out);
+void group_dist_plan_release(ntt_dist_plan *dp);
 
 }  // namespace ntt
 
@@ -88,6 +113,14 @@ struct ntt_ctx {
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
     std::mutex mu;                                    // serialises calls on this handle
+    // A context over several devices (ntt_ctx_create with ndev > 1, multidev.cpp): one ordinary single-device context
+    // per SLOT; device ids may repeat (a one-GPU box rehearses {0, 0, 0, 0}).  The group itself owns no stream: plans,
+    // products and transforms made from it are sharded over the slots by ntt::partition.  peer_ok: every pair of
+    // distinct devices has peer access enabled, so a kernel on one slot may load from and store to another's arrays.
+    std::vector<ntt_ctx *> sub;
+    bool peer_ok = true;
+    ntt::GroupCrt *gcrt = nullptr;
+    bool is_group() const { return !sub.empty(); }
 
     // per-kernel timing (bench.py roofline block)
     bool timing = false;
@@ -156,6 +189,8 @@ struct ntt_plan {
     bool col16_fwd = false, col16_inv = true;
     ntt::DeviceBuffer work0, work1;
     std::vector<void *> owned;          // device allocations to free
+    // plan of a multi-device context: one plan per slot, each sized for that slot's share of the batch
+    std::vector<ntt_plan *> shard;
 };
 
 // Distributed transform of length L = 2^lgL over `world` ranks (include/ntt_amd.h, ntt_dist_*):
@@ -169,4 +204,17 @@ struct ntt_dist_plan {
     int lgL = 0, world = 1, rank = 0;
     uint32_t S = 0;
     std::vector<unsigned char> scale;      // world^-1 (inverse column pass, row 0)
+    // plan of a multi-device context (world = its slots): the pieces of EVERY rank (part[r] lives on slot r) and what
+    // the in-library exchange needs per slot (ntt_dist_forward / ntt_dist_inverse, multidev.cpp)
+    std::vector<ntt_dist_plan *> part;
+    struct GroupSlot {
+        ntt::DeviceBuffer held, sendbuf, rowbuf;          // [world][S/world] staging (copy transports), local inverse output
+        hipStream_t copy_in = nullptr, copy_out = nullptr;
+        hipEvent_t start = nullptr, ready = nullptr, done = nullptr, fin = nullptr, out_done = nullptr;
+        std::vector<hipEvent_t> ev_in, ev_k;              // per column chunk
+    };
+    std::vector<GroupSlot> gslot;
+    int transport = 0;                     // 0 p2p (peer loads + peer stores), 1 copy-in + peer stores, 2 copies both ways
+    int chunks = 1;                        // column chunks of the copy transports (exchange of chunk c + 1 beside the kernel of chunk c)
+    std::mutex gmu;
 };

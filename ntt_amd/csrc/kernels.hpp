@@ -204,6 +204,21 @@ void launch_crt_reduce_all(const uint64_t *a, const uint64_t *b, uint32_t *ra, u
 void launch_crt_merge(const uint32_t *const res[4], uint64_t *out, size_t n, const CrtConsts &cc,
                       hipStream_t s);
 
+// ---- one transform split over the devices of a multi-device context (kernels_dist.hip) --------------------
+constexpr int kMaxDistWorld = 16;        // G-point column transform in registers: G = 2, 4, 8, 16
+template <class MM>
+struct DistColArgs {
+    const uint32_t *in[kMaxDistWorld];   // in[i1][j]: point i1 of column j of this slot's piece (a peer's array, or local staging)
+    uint32_t *out[kMaxDistWorld];        // out[k1][j]: row k1 goes to slot k1 (its array, or a local send array)
+    const typename MM::tw_t *tw;         // [G][cols]: w_L^(+-(h * cols + j) * k1); the inverse table carries G^-1
+    typename MM::tw_t scale0;            // inverse: multiplier of row 0 (G^-1)
+    int use_scale0;
+    uint32_t cols;                       // columns of this slot's piece = S / G (row length of tw)
+    uint32_t col0, ncols;                // this launch: columns [col0, col0 + ncols), ncols a multiple of 256
+    Roots64<MM> roots;                   // forward or inverse w_64 powers (the G-th root is a stride of them)
+};
+bool launch_dist_col(int kind, bool lazy, int logG, bool inverse, const void *args, const ModParams &mp, hipStream_t s);
+
 // ---- direct 64-bit path (kernels_u64.hip): one NTT-friendly prime p < 2^62, Montgomery R = 2^64 ---------
 struct ModParams64 {
     uint64_t p, p2, nprime;              // nprime = -p^-1 mod 2^64

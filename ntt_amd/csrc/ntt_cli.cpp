@@ -12,6 +12,10 @@
 //           [--pack]      convert "<id>.in" / "<id>.out" to the packed "<id>.inb" / "<id>.outb" and exit
 //           [--bin]       read, check and write the packed files instead of the text ones
 //           [--direct64]  moduli above 2^31: one 64-bit transform (ntt_plan64) instead of the 4-prime CRT
+//           [--devices 0,1,2,3]  the rank layout of main-mpi.cc:642-819 inside one process: a multi-device context
+//                         with one slot per listed GPU; cases with a 32-bit modulus run on slot 0 while the others idle
+//                         (main-mpi.cc:710-738), a larger modulus puts CRT prime k on slot k / ceil(4 / slots) and
+//                         exchanges coefficient slices before the merge (:739-797; multidev.cpp)
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -28,6 +32,7 @@ int main(int argc, char **argv)
     std::string data = "./nttdata", out = "./files";
     int begin = 0, end = 4, epochs = 50, kind = NTT_MODMUL_MONTGOMERY;
     bool pack = false, bin = false, direct64 = false;
+    std::vector<int> devices{0};
     for (int i = 1; i < argc; ++i) {
         auto need = [&](const char *flag) -> const char * {
             if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", flag); std::exit(2); }
@@ -42,6 +47,16 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--pack")) pack = true;
         else if (!std::strcmp(argv[i], "--bin")) bin = true;
         else if (!std::strcmp(argv[i], "--direct64")) direct64 = true;
+        else if (!std::strcmp(argv[i], "--devices")) {
+            devices.clear();
+            for (const char *c = need("--devices"); *c; ) {
+                char *e = nullptr;
+                devices.push_back((int)std::strtol(c, &e, 10));
+                if (e == c) { std::fprintf(stderr, "--devices takes a comma-separated list of device ids\n"); return 2; }
+                c = *e == ',' ? e + 1 : e;
+            }
+            if (devices.empty()) { std::fprintf(stderr, "--devices: empty list\n"); return 2; }
+        }
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
     if (epochs < 1) epochs = 1;
@@ -55,9 +70,9 @@ int main(int argc, char **argv)
         }
         return failed ? 1 : 0;
     }
-    ntt_ctx *ctx = nullptr;
-    int dev = 0;
-    if (ntt_ctx_create(&dev, 1, &ctx) != NTT_OK) {
+    ntt_ctx *top = nullptr, *ctx = nullptr;               // top: every slot (large-modulus products); ctx: slot 0 (the rest)
+    if (ntt_ctx_create(devices.data(), (int)devices.size(), &top) != NTT_OK ||
+        ntt_ctx_device(top, 0, &ctx, nullptr) != NTT_OK || hipSetDevice(devices[0]) != hipSuccess) {
         std::fprintf(stderr, "ntt_ctx_create: %s\n", ntt_last_error());
         return 1;
     }
@@ -137,7 +152,7 @@ int main(int argc, char **argv)
         } else {
             for (int e = 0; e < epochs + 1; ++e) {
                 auto t0 = std::chrono::high_resolution_clock::now();
-                rc = ntt_crt_multiply(ctx, a.data(), b.data(), ab.data(), n, p);
+                rc = ntt_crt_multiply(top, a.data(), b.data(), ab.data(), n, p);
                 auto t1 = std::chrono::high_resolution_clock::now();
                 if (rc != NTT_OK) break;
                 if (e > 0) total_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
@@ -162,6 +177,6 @@ int main(int argc, char **argv)
         if ((bin ? ntt_write_case_bin(out.c_str(), id, abw, n, p, width) : ntt_write_case(out.c_str(), id, ab.data(), n)) != NTT_OK)
             std::fprintf(stderr, "case %d not written: %s\n", id, ntt_last_error());
     }
-    ntt_ctx_destroy(ctx);
+    ntt_ctx_destroy(top);
     return bad ? 1 : 0;
 }

@@ -200,6 +200,7 @@ extern "C" int ntt_poly_multiply_stream(ntt_plan *pl, const uint32_t *a, const u
                                         size_t ab_stride, size_t count)
 try {
     if (!pl || !a || !b || !ab) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_stream: null argument");
+    if (!pl->shard.empty()) return fail(NTT_ERR_UNSUPPORTED, "ntt_poly_multiply_stream: not for plans of a multi-device context (stream per slot: ntt_ctx_device)");
     if (count == 0) return NTT_OK;
     if (pl->negacyclic) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_stream: not for negacyclic plans");
     const size_t n = (size_t)pl->n, out_len = 2 * n - 1;

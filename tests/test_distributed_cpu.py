@@ -27,6 +27,34 @@ def test_partition_matches_reference_mpi_rule():
     assert shard.rank_seed(100, 3, 1024) == 100 + 3 * 1024
 
 
+def test_library_partition_is_the_same_rule():
+    """The multi-device contexts shard inside the C++ library (multidev.cpp): its rule, exported as ntt_partition,
+    against the Python one and the reference's arithmetic (main-mpi.cc:657-660) for the four primes."""
+    import ntt_amd
+    for total in (0, 1, 4, 7, 32, 256, 1024, 8192):
+        for world in (1, 2, 3, 4, 8, 16, 64):
+            for r in range(world):
+                assert ntt_amd.partition(total, world, r) == shard.partition(total, world, r), (total, world, r)
+    for size in (1, 2, 3, 4, 5, 8):
+        mpp = (4 + size - 1) // size                       # mods_per_process
+        for rank in range(size):
+            start, end = min(rank * mpp, 4), min(rank * mpp + mpp, 4)
+            assert ntt_amd.partition(4, size, rank) == (start, max(0, end - start))
+    with pytest.raises(ntt_amd.NttError):
+        ntt_amd.partition(4, 2, 2)
+
+
+def test_multi_device_context_needs_gpus():
+    """ntt_ctx_create with ndev > 1 on a box without a GPU: a clean NTT_ERR_HIP, no crash, no CPU fallback."""
+    import torch
+    import ntt_amd
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(ntt_amd.NttError) as e:
+        ntt_amd.Context(devices=[0, 0])
+    assert e.value.code == ntt_amd.ERR_HIP
+
+
 def test_two_ranks_gloo(tmp_path):
     out = tmp_path / "result.json"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")

@@ -104,3 +104,29 @@ def test_bench_gpus_flag_on_one_gpu():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
     assert j["config"]["batch_per_gpu"] == 96 and j["roofline"]["kernel"] in ("row_mul", "col_fwd", "col_inv")
+    # the other sharded workloads behind the headline loop: prime-per-rank CRT with its exchange, RNS limbs
+    # per rank, one 2^26-point transform split over the two ranks -- each timed, each checked on every rank
+    also = j["also"]
+    assert also["checks"] == "ok", also
+    for key in ("crt4_n2p17_ms", "crt4_GBps", "rns_32x256_n2p16_ms", "rns_products_per_s", "ntt2p26_fwd_inv_ms", "ntt2p26_GBps"):
+        assert also[key] > 0, key
+    assert also["crt4_primes_per_rank"] == 2 and also["rns_limbs_per_rank"] == 16
+    assert also["crt4_sent_bytes_per_rank"] == ((2 * 131072 - 1 + 1) // 2) * (4 * 2 + 8)
+    assert also["ntt2p26_sent_bytes_per_rank"] == 4 * (1 << 24) * 4
+    assert j["roofline"]["binding"] == "valu-int" and 0 < j["roofline"]["valu_frac_of_coupled_peak"] < 1.2
+
+
+def test_bench_also_block_one_rank():
+    """The default (one GPU) bench line carries the same block: CRT through CrtExchange at world 1, 8192 RNS products,
+    the single-GPU 2^26 transform."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--batch", "96", "--sustained-seconds", "0", "--no-one-lane"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    also = j["also"]
+    assert also["checks"] == "ok" and also["ntt2p26_sent_bytes_per_rank"] == 0 and also["crt4_sent_bytes_per_rank"] == 0, also
+    assert also["rns_products_per_s"] > 1e5 and also["crt4_n2p17_ms"] < 5 and also["ntt2p26_fwd_inv_ms"] < 50
