@@ -310,10 +310,16 @@ def also_block(args, group, rank, world, local_rank):
                 failed.append("rns identity")
                 break
         if rank == 0:
+            # exact coefficients at both ends of one row (Python integers).  The CPU oracle restates the reference, whose
+            # generator is the literal 3 and whose Montgomery body pads to a power of FOUR (main-montgomery.cc:257,
+            # :317-321): neither holds for primes that are only = 1 mod 2^17, so this workload has no oracle row
             r = polys - 1
-            if not np.array_equal(rab[r].cpu().numpy().view(np.uint32),
-                                  orc.poly_multiply(ra[r].cpu().numpy().view(np.uint32), rb[r].cpu().numpy().view(np.uint32), pl_p)):
-                failed.append("rns oracle")
+            ai, bi, ci = ra[r].cpu().tolist(), rb[r].cpu().tolist(), rab[r].cpu().tolist()
+            for k in list(range(12)) + list(range(2 * n - 1 - 12, 2 * n - 1)):
+                lo, hi = max(0, k - (n - 1)), min(k, n - 1)
+                if sum(ai[i] * bi[k - i] for i in range(lo, hi + 1)) % pl_p != ci[k] % (1 << 32):
+                    failed.append("rns exact coefficients")
+                    break
     t = timed(rns, 3)
     out["rns_32x256_n2p16_ms"] = 1e3 * t
     out["rns_products_per_s"] = limbs * polys / t

@@ -188,3 +188,34 @@ def test_crt_multiply_routes_to_direct_plan(nt, monkeypatch):
                 want[i + j] += ai * int(b[j])
         assert [int(x) for x in got] == [w % p64 for w in want], p64
     c.close()
+
+
+@pytest.mark.parametrize("n", [40000, 131072])
+def test_forward_column_pass_prefetch_variant(nt, monkeypatch, n):
+    """The walking first forward pass with the next product's loads in flight (col_walk_prefetch_kernel, the default for
+    batches above 16 at column levels of 32 / 64 points) against the plain walking kernel (NTT_AMD_COL_PREFETCH=0) and
+    the oracle: Montgomery and Barrett, a lazy and a strict prime, a batch that leaves workgroups with 2 and 3 products."""
+    import torch
+    batch = 41
+    for p, kind in ((998244353, nt.MONTGOMERY), (998244353, nt.BARRETT), (1224736769, nt.MONTGOMERY), (469762049, nt.BARRETT)):
+        rng = np.random.default_rng(n + p % 1000 + kind)
+        a = rng.integers(0, p, size=(batch, n), dtype=np.int64).astype(np.uint32)
+        b = rng.integers(0, p, size=(batch, n), dtype=np.int64).astype(np.uint32)
+        a[0, :] = p - 1
+        b[0, :] = p - 1
+        da, db = torch.from_numpy(a.view(np.int32)).cuda(), torch.from_numpy(b.view(np.int32)).cuda()
+        outs = []
+        c = nt.Context(0)
+        plan = c.plan(p, n, batch, kind)
+        for flag in ("1", "0"):
+            monkeypatch.setenv("NTT_AMD_COL_PREFETCH", flag)
+            out = torch.full((batch, 2 * n - 1), -1, dtype=torch.int32, device="cuda")
+            plan.multiply(da, db, out=out, batch=batch)
+            c.synchronize()
+            outs.append(out)
+        plan.close()
+        c.close()
+        assert torch.equal(outs[0], outs[1]), (p, kind)
+        got = outs[0].cpu().numpy().view(np.uint32)
+        for r in (0, 16, 17, 33, batch - 1):                # first, second and third product of a workgroup's walk
+            assert np.array_equal(got[r], orc.poly_multiply(a[r], b[r], p, kind="barrett")), (p, kind, r)
