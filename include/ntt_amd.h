@@ -257,9 +257,11 @@ int ntt_dist_local_length(const ntt_dist_plan *plan);
  * NTT_AMD_DIST_TRANSPORT (read at plan creation) = "copyin": the first exchange is hipMemcpyPeerAsync per peer slice
  * into a local array, cut into NTT_AMD_DIST_CHUNKS (4) column chunks so that the copies of chunk c + 1 run beside the
  * kernel of chunk c, the second stays peer stores; = "copy": both exchanges are peer copies (the default without
- * peer access).  Queued on the slots' streams: ntt_ctx_synchronize(ctx) waits.  The arrays must be complete when the
+ * peer access); = "rccl": both exchanges are grouped ncclSend / ncclRecv pairs on one communicator per slot
+ * (librccl is opened with dlopen for this transport only; it needs distinct devices, so a one-GPU rehearsal with
+ * repeated ids is refused with NTT_ERR_UNSUPPORTED -- this transport has never moved data by us).  Queued on the slots' streams: ntt_ctx_synchronize(ctx) waits.  The arrays must be complete when the
  * call is made (it orders itself only against earlier calls on the same plan).
- * ntt_dist_plan_transport reports the transport in use (0 p2p, 1 copyin, 2 copy; -1 for a single-device plan). */
+ * ntt_dist_plan_transport reports the transport in use (0 p2p, 1 copyin, 2 copy, 3 rccl; -1 for a single-device plan). */
 int ntt_dist_forward(ntt_dist_plan *plan, const uint32_t *const *in, uint32_t *const *out);
 int ntt_dist_inverse(ntt_dist_plan *plan, const uint32_t *const *in, uint32_t *const *out);
 int ntt_dist_plan_transport(const ntt_dist_plan *plan, int *transport, int *chunks);

@@ -466,7 +466,7 @@ class DistPlan:
         """(name, column chunks) of the in-library exchange of a multi-device plan; (None, 0) for one rank's plan."""
         t, c = C.c_int(), C.c_int()
         _check(_lib.ntt_dist_plan_transport(self._h, C.byref(t), C.byref(c)))
-        return ({0: "p2p", 1: "copyin", 2: "copy"}.get(t.value), c.value)
+        return ({0: "p2p", 1: "copyin", 2: "copy", 3: "rccl"}.get(t.value), c.value)
 
     def _blocks(self, arrays):
         if len(arrays) != self.world:

@@ -72,6 +72,21 @@ struct Ops {
     }
 };
 
+// (u - v) brought back into range by adding `bound` when it is negative: u in [0, bu), v in [0, bound) -> [0, max(bu, bound)).
+// Ops::sub with the bound as an argument (borrow-out + select, as csub() in modarith.hpp).
+__device__ __forceinline__ uint32_t sub_mod(uint32_t u, uint32_t v, uint32_t bound)
+{
+#if !defined(NTT_CSUB_MIN)
+    uint32_t d0, r;
+    asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_add_u32 %1, %4, %0\n\tv_cndmask_b32 %1, %0, %1, vcc"
+        : "=&v"(d0), "=&v"(r) : "v"(u), "v"(v), "s"(bound) : "vcc");
+    return r;
+#else
+    const uint32_t d = u - v, e = d + bound;
+    return u < v ? e : d;
+#endif
+}
+
 // ---- buffer addressing ---------------------------------------------------------------------------
 // The column kernels read and write rows that are S elements apart.  Through a buffer descriptor
 // (base + size in four SGPRs) a row is reached with a 32-bit per-lane byte offset plus a scalar
@@ -132,6 +147,40 @@ __host__ __device__ constexpr int bitrev_c(int x, int bits)
     return r;
 }
 
+// Range bookkeeping of the WIDE transform below, at compile time.  Values are tracked as multiples of p: a product is
+// below 2p, the sum of two values below 2p is kept unreduced (below 4p), a sum that could reach 8p is reduced once by
+// 4p; csub[s][i] says whether the sum written to position i in stage s needs that reduction, subb[s][i] which multiple
+// of p the twiddle-free difference written to position i adds back when it is negative.
+template <int LOGN, bool HALF>
+struct WidePlan {
+    static constexpr int N = 1 << LOGN;
+    static constexpr int ST = LOGN > 0 ? LOGN : 1;
+    bool csub[ST][N];
+    int subb[ST][N];
+    constexpr WidePlan() : csub{}, subb{}
+    {
+        int b[N] = {};
+        for (int i = 0; i < N; ++i) b[i] = 2;
+        for (int s = 0; s < LOGN; ++s) {
+            const int half = N >> (s + 1);
+            for (int blk = 0; blk < N; blk += 2 * half)
+                for (int j = 0; j < half; ++j) {
+                    const int lo = blk + j, hi = lo + half;
+                    if (HALF && s == 0) {                     // v == 0: the sum is u, the difference u or u * w
+                        b[hi] = j == 0 ? b[lo] : 2;
+                        continue;
+                    }
+                    if (s == LOGN - 1) continue;              // last stage: loose outputs below 8p
+                    const int bu = b[lo], bv = b[hi];
+                    if (bu + bv > 4) { csub[s][lo] = true; b[lo] = 4; }
+                    else b[lo] = bu + bv;
+                    if (j == 0) { subb[s][hi] = bv; b[hi] = bu > bv ? bu : bv; }
+                    else b[hi] = 2;
+                }
+        }
+    }
+};
+
 // In-register N-point transform, N = 2^LOGN <= 64: natural order in, natural order out,
 // X[k] = sum_j x[j] * w^(jk) with w = roots.w[32/(N/2)] (i.e. the primitive N-th root whose
 // powers are the stride-(64/N) entries of the w_64 table; forward or inverse table).
@@ -141,13 +190,21 @@ __host__ __device__ constexpr int bitrev_c(int x, int bits)
 // ([0, 4p) lazy, [0, 2p) strict).  Every consumer either multiplies the value by a twiddle
 // (mul_tw takes any u32 and reduces for free) or applies Ops::tighten -- this removes 16 of the
 // ~47 conditional subtractions of a 16-point transform.
-template <class MM, bool LAZY, int LOGN, bool HALF, bool LOOSE = false>
+// WIDE (needs LAZY, LOOSE and 8p <= 2^32, i.e. p < 2^29 -- the reference's three shipped primes 7340033, 104857601,
+// 469762049, main-montgomery.cc:301-306, and the CRT prime 469762049, main-openmp.cc:654): inputs in [0, 2p), values
+// inside the transform may grow to 4p, a sum is reduced only where it could reach 8p (WidePlan), outputs lie in
+// [0, 8p).  16 of the 24 conditional subtractions a 16-point LOOSE transform still has are gone (2 of 7 instructions
+// of those butterflies).  The signed multiply-add butterfly stays valid: |u - v| < 4p < 2^31 and |u - v| w < 4p^2 <= p 2^31.
+template <class MM, bool LAZY, int LOGN, bool HALF, bool LOOSE = false, bool WIDE = false>
 __device__ __forceinline__ void reg_ntt(uint32_t (&x)[1 << LOGN], const Roots64<MM> &roots,
                                         const ModParams &m)
 {
     using O = Ops<MM, LAZY>;
     constexpr int N = 1 << LOGN;
+    static_assert(!WIDE || (LAZY && LOOSE), "the wide-range transform is a lazy transform with loose outputs");
     if constexpr (LOGN == 0) return;
+    constexpr WidePlan<WIDE ? LOGN : 0, HALF> wp{};
+    const uint32_t p4 = m.p2 << 1;                    // used by WIDE only
 #pragma unroll
     for (int s = 0; s < LOGN; ++s) {
         const int half = N >> (s + 1);
@@ -160,6 +217,14 @@ __device__ __forceinline__ void reg_ntt(uint32_t (&x)[1 << LOGN], const Roots64<
                 if (HALF && s == 0) {
                     // v == 0: sum = u, difference = u
                     x[blk + j + half] = (j == 0) ? u : O::mul_tw(u, roots.w[j * step], m);
+                } else if (WIDE && s == LOGN - 1) {
+                    x[blk + j] = u + v;                              // below 8p
+                    x[blk + j + half] = u - v + p4;                  // (0, 8p)
+                } else if (WIDE) {
+                    const uint32_t sum = u + v;
+                    x[blk + j] = wp.csub[WIDE ? s : 0][WIDE ? blk + j : 0] ? csub(sum, p4) : sum;
+                    if (j == 0) x[blk + j + half] = sub_mod(u, v, wp.subb[WIDE ? s : 0][WIDE ? blk + j + half : 0] == 4 ? p4 : m.p2);
+                    else x[blk + j + half] = MM::mul_tw_diff(u, v, roots.w[j * step], p4, m);   // [0, 2p)
                 } else if (LOOSE && s == LOGN - 1) {
                     x[blk + j] = u + v;                              // half == 1: j == 0 only
                     x[blk + j + half] = O::sub_raw(u, v, m);
@@ -176,6 +241,12 @@ __device__ __forceinline__ void reg_ntt(uint32_t (&x)[1 << LOGN], const Roots64<
     for (int i = 0; i < N; ++i) y[bitrev_c(i, LOGN)] = x[i];
 #pragma unroll
     for (int i = 0; i < N; ++i) x[i] = y[i];
+}
+
+// loose output of a WIDE transform, [0, 8p), to [0, 2p)
+__device__ __forceinline__ uint32_t tighten_wide(uint32_t x, const ModParams &m)
+{
+    return csub(csub(x, m.p2 << 1), m.p2);
 }
 
 }  // namespace ntt

@@ -4,6 +4,7 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <exception>
 #include <new>
 #include <cstdio>
@@ -85,6 +86,27 @@ int take_launch_error()
         if (e_ != hipSuccess)                                                                  \
             return ntt::fail(NTT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));  \
     } while (0)
+
+// Wait for the context's stream.  The harness calls one product and waits for it (main-montgomery.cc:336-346): there the
+// wake-up of a blocked host thread is a large part of what it measures (14 us for the n = 4 case whose kernel runs 3 us), so
+// the wait first polls the stream for up to NTT_AMD_SYNC_SPIN_US microseconds (default 200; 0 = block at once) and only
+// then blocks in hipStreamSynchronize.
+int sync_stream(ntt_ctx *cx)
+{
+    static const long spin_us = [] { const char *e = std::getenv("NTT_AMD_SYNC_SPIN_US"); return e ? std::atol(e) : 200L; }();
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t e = hipStreamQuery(cx->stream);
+            if (e == hipSuccess) return NTT_OK;
+            if (e != hipErrorNotReady) return fail(NTT_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+            (void)hipGetLastError();                       // "not ready" is sticky in the runtime's last-error slot
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= spin_us) break;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(cx->stream));
+    return NTT_OK;
+}
 
 int DeviceBuffer::ensure(size_t need)
 {
@@ -334,7 +356,7 @@ static void col_pass(ntt_plan *pl, int level, bool inverse, bool half_in, const 
         launch_col16(pl->kind, pl->lazy, pl->level_log[level], inverse, half_in, &a, pl->mp,
                      pl->L >> pl->level_log[level], batch, nops, cx->cur);
     else
-        launch_col(pl->kind, pl->lazy, pl->level_log[level], inverse, half_in, &a, pl->mp,
+        launch_col(pl->kind, pl->lazy_mode(), pl->level_log[level], inverse, half_in, &a, pl->mp,
                    pl->L >> pl->level_log[level], batch, nops, cx->cur);
     cx->end();
 }
@@ -362,13 +384,13 @@ static void row_pass(ntt_plan *pl, int which, const uint32_t *a0, const uint32_t
     hipEvent_t e0 = nullptr, e1 = nullptr;
     static const bool ext_events = [] { const char *e = std::getenv("NTT_AMD_EXT_EVENTS"); return !(e && e[0] == '0'); }();
     if (which == 0 && ext_events && cx->begin_ext(K_ROW_MUL, &e0, &e1)) {
-        launch_row_mul_timed(pl->kind, pl->lazy, &a, pl->mp, rows, cx->cur, e0, e1);
+        launch_row_mul_timed(pl->kind, pl->lazy_mode(), &a, pl->mp, rows, cx->cur, e0, e1);
         return;
     }
     cx->begin(which == 0 ? K_ROW_MUL : which == 1 ? K_ROW_FWD : K_ROW_INV);
-    if (which == 0) launch_row_mul(pl->kind, pl->lazy, &a, pl->mp, rows, cx->cur);
-    else if (which == 1) launch_row_fwd(pl->kind, pl->lazy, &a, pl->mp, rows, cx->cur);
-    else launch_row_inv(pl->kind, pl->lazy, &a, pl->mp, rows, cx->cur);
+    if (which == 0) launch_row_mul(pl->kind, pl->lazy_mode(), &a, pl->mp, rows, cx->cur);
+    else if (which == 1) launch_row_fwd(pl->kind, pl->lazy_mode(), &a, pl->mp, rows, cx->cur);
+    else launch_row_inv(pl->kind, pl->lazy_mode(), &a, pl->mp, rows, cx->cur);
     cx->end();
 }
 
@@ -419,7 +441,7 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
         }
         ntt_ctx *cx = pl->ctx;
         cx->begin(K_ROW_MUL);
-        launch_row_product(pl->kind, pl->lazy, &ra, pl->mp, (unsigned)batch, cx->cur);
+        launch_row_product(pl->kind, pl->lazy_mode(), &ra, pl->mp, (unsigned)batch, cx->cur);
         cx->end();
         return NTT_OK;
     }
@@ -817,8 +839,7 @@ try {
     if (!ctx) return fail(NTT_ERR_INVALID, "null context");
     if (ctx->is_group()) return group_ctx_synchronize(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return NTT_OK;
+    return sync_stream(ctx);
 }
 NTT_CATCH_STATUS
 
@@ -952,6 +973,10 @@ static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_ki
     pl->lazy = p < (1u << 30);
     if (const char *e = std::getenv("NTT_AMD_FORCE_STRICT"))
         if (e[0] == '1') pl->lazy = false;
+    // 8p <= 2^32: the wide-range transforms (NTT_AMD_WIDE=0 keeps the [0, 2p) kernels; A/B runs and tests of both)
+    pl->wide8 = pl->lazy && p < (1u << 29);
+    if (const char *e = std::getenv("NTT_AMD_WIDE"))
+        if (e[0] == '0') pl->wide8 = false;
     // forward column pass: the register kernel wins in a full launch, the LDS-staged one (four times the
     // workgroups, a quarter of the work per thread) when a launch holds a few products only
     // (single product: 9.7 -> 8.2 us, tools/time_single.py)
@@ -1105,9 +1130,9 @@ static int multiply_entry(ntt_plan *pl, const uint32_t *a, const uint32_t *b, ui
     if (int lrc_ = ntt::take_launch_error()) return lrc_;
     if (!dab) {
         HIP_TRY(hipMemcpyAsync(ab, pab, out_elems * 4, hipMemcpyDeviceToHost, cx->stream));
-        HIP_TRY(hipStreamSynchronize(cx->stream));
+        if (int src_ = sync_stream(cx)) return src_;
     } else if (!da || !db) {
-        HIP_TRY(hipStreamSynchronize(cx->stream));     // host inputs may be reused by the caller
+        if (int src_ = sync_stream(cx)) return src_;   // host inputs may be reused by the caller
     }
     return NTT_OK;
 }

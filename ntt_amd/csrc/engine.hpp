@@ -51,6 +51,7 @@ const char *last_error_cstr();
 // NTT_OK, or NTT_ERR_INTERNAL (and the message) if a dispatcher skipped a launch since the last call; clears the mark
 int take_launch_error();
 bool is_device_ptr(const void *p);
+int sync_stream(ntt_ctx *cx);              // engine.cpp: poll briefly, then block
 bool is_prime64(uint64_t n);              // direct64.cpp: deterministic Miller-Rabin
 
 // Where a multiply keeps the intermediates of its passes when they are not the plan's own work buffers:
@@ -159,6 +160,8 @@ struct ntt_plan {
     int n = 0, logL = 0, batch = 0, kind = 0, chunk = 1, lanes = 1;
     uint32_t L = 0;
     bool lazy = false;
+    bool wide8 = false;                 // p < 2^29: the row kernels and forward register column passes keep sums unreduced up to 4p (device_ntt.hpp, WIDE)
+    int lazy_mode() const { return wide8 ? 2 : lazy ? 1 : 0; }
     ntt::ModParams mp{};
     // 4-step structure (L >= 8192): column levels, outermost first
     int nlevels = 0;
@@ -214,7 +217,8 @@ struct ntt_dist_plan {
         std::vector<hipEvent_t> ev_in, ev_k;              // per column chunk
     };
     std::vector<GroupSlot> gslot;
-    int transport = 0;                     // 0 p2p (peer loads + peer stores), 1 copy-in + peer stores, 2 copies both ways
+    int transport = 0;                     // 0 p2p (peer loads + peer stores), 1 copy-in + peer stores, 2 copies both ways, 3 RCCL send / recv both ways
+    std::vector<void *> comms;             // transport 3: one ncclComm_t per slot (ncclCommInitAll)
     int chunks = 1;                        // column chunks of the copy transports (exchange of chunk c + 1 beside the kernel of chunk c)
     std::mutex gmu;
 };

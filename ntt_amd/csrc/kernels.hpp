@@ -119,8 +119,10 @@ struct CrtConsts {
 // (engine.cpp: take_launch_error), so a skipped launch can never return NTT_OK over stale work buffers.
 void note_unsupported_launch(const char *what, int value);
 
-// kind: 0 Montgomery, 1 Barrett; lazy: values kept in [0,2p) (needs 4p <= 2^32)
-void launch_col(int kind, bool lazy, int logN1, bool inverse, bool half_in, const void *args,
+// kind: 0 Montgomery, 1 Barrett; lazy: 0 strict [0, p); 1 values kept in [0, 2p) (needs 4p <= 2^32); 2 (row kernels and
+// the forward register column pass; everything else treats it as 1) = 1 with the wide-range transforms of
+// device_ntt.hpp (needs 8p <= 2^32)
+void launch_col(int kind, int lazy, int logN1, bool inverse, bool half_in, const void *args,
                 const ModParams &mp, unsigned cols_per_row, unsigned batch, unsigned nops,
                 hipStream_t s);
 // the zero-padded first forward level reading u64 operands (Montgomery kernels, 32 or 64 points): false if no such kernel
@@ -129,15 +131,15 @@ bool launch_col_u64in(bool lazy, int logN1, const void *args, const ModParams &m
 void launch_col16(int kind, bool lazy, int logN1, bool inverse, bool half_in, const void *args,
                   const ModParams &mp, unsigned cols_per_row, unsigned batch, unsigned nops,
                   hipStream_t s);
-void launch_row_mul(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);
+void launch_row_mul(int kind, int lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);
 // the same launch with the kernel's own start / stop events (hipExtLaunchKernelGGL): kernel timing without the
 // extra queue packets of hipEventRecord around it
-void launch_row_mul_timed(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s,
+void launch_row_mul_timed(int kind, int lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s,
                           hipEvent_t start, hipEvent_t stop);
 // L = 4096 exactly: the whole product of one pair in the row kernel (args: Row4096Args<MM>)
-void launch_row_product(int kind, bool lazy, const void *args, const ModParams &mp, unsigned batch, hipStream_t s);
-void launch_row_fwd(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);
-void launch_row_inv(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);
+void launch_row_product(int kind, int lazy, const void *args, const ModParams &mp, unsigned batch, hipStream_t s);
+void launch_row_fwd(int kind, int lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);
+void launch_row_inv(int kind, int lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s);
 void launch_small(int kind, bool lazy, const void *args, const ModParams &mp, unsigned batch, hipStream_t s);
 
 // dst[row][perm(i)] = src[row][i] (to_natural) or dst[row][i] = src[row][perm(i)]; perm is the

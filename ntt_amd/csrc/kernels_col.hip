@@ -18,9 +18,10 @@
 namespace ntt {
 
 // one thread, one column of batch row `by`
-template <class MM, bool LAZY, int LOGN1, bool INVERSE, bool HALF, bool U64IN>
+template <class MM, bool LAZY, int LOGN1, bool INVERSE, bool HALF, bool U64IN, bool WIDE = false>
 __device__ __forceinline__ void col_body(const ColArgs<MM> &a, const ModParams &m, const uint32_t by)
 {
+    static_assert(!WIDE || !INVERSE, "the wide-range transform serves the forward passes");
     using O = Ops<MM, LAZY>;
     using tw_t = typename MM::tw_t;
     constexpr int N1 = 1 << LOGN1;
@@ -65,9 +66,9 @@ __device__ __forceinline__ void col_body(const ColArgs<MM> &a, const ModParams &
         for (int k1 = 1; k1 < N1; ++k1)
             x[k1] = O::mul_tw(x[k1], buf_load_tw<tw_t>(rtw, twoff, (uint32_t)k1 << twsh), m);
     }
-    reg_ntt<MM, LAZY, LOGN1, HALF, true>(x, a.roots, m);          // loose outputs
+    reg_ntt<MM, LAZY, LOGN1, HALF, true, WIDE>(x, a.roots, m);    // loose outputs (WIDE: below 8p)
     if constexpr (!INVERSE) {
-        x[0] = O::tighten(x[0], m);
+        x[0] = WIDE ? tighten_wide(x[0], m) : O::tighten(x[0], m);
 #pragma unroll
         for (int k1 = 1; k1 < N1; ++k1)
             x[k1] = O::mul_tw(x[k1], buf_load_tw<tw_t>(rtw, twoff, (uint32_t)k1 << twsh), m);
@@ -95,12 +96,12 @@ __device__ __forceinline__ void col_body(const ColArgs<MM> &a, const ModParams &
 // A launch covers the batch in grid.y; a WALKING launch (a.loop_batch > 0, see launch_col) has fewer workgroups than
 // batch rows and each takes rows blockIdx.y, blockIdx.y + gridDim.y, ...: what does not depend on the row -- the
 // column's 4-step twiddles above all -- is then loaded once per workgroup.
-template <class MM, bool LAZY, int LOGN1, bool INVERSE, bool HALF, bool U64IN = false>
+template <class MM, bool LAZY, int LOGN1, bool INVERSE, bool HALF, bool U64IN = false, bool WIDE = false>
 __global__ void __launch_bounds__(256) col_kernel(const ColArgs<MM> a, const ModParams m)
 {
     uint32_t by = blockIdx.y;
     do {
-        col_body<MM, LAZY, LOGN1, INVERSE, HALF, U64IN>(a, m, by);
+        col_body<MM, LAZY, LOGN1, INVERSE, HALF, U64IN, WIDE>(a, m, by);
         by += gridDim.y;
     } while (by < a.loop_batch);
 }
@@ -110,7 +111,7 @@ __global__ void __launch_bounds__(256) col_kernel(const ColArgs<MM> a, const Mod
 // are in flight under its butterflies and stores (two waves per SIMD cannot hide them otherwise: the kernel sat at
 // 0.117 VALU instructions per SIMD-cycle).  The column's 4-step twiddles stay in registers for the walk.
 // Plain cyclic transform only (no twist, intermediate output): the multiply path's first pass.
-template <class MM, bool LAZY, int LOGN1>
+template <class MM, bool LAZY, int LOGN1, bool WIDE = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) col_walk_prefetch_kernel(const ColArgs<MM> a, const ModParams m)
 {
     using O = Ops<MM, LAZY>;
@@ -151,8 +152,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             for (int i1 = 0; i1 < H; ++i1) nx[i1] = buf_load_nt(rin, vo + ((uint32_t)i1 << rowsh), 0);
         }
         __builtin_amdgcn_sched_barrier(0);                            // the loads stay in front of the arithmetic
-        reg_ntt<MM, LAZY, LOGN1, true, true>(x, a.roots, m);
-        x[0] = O::tighten(x[0], m);
+        reg_ntt<MM, LAZY, LOGN1, true, true, WIDE>(x, a.roots, m);
+        x[0] = WIDE ? tighten_wide(x[0], m) : O::tighten(x[0], m);
 #pragma unroll
         for (int k1 = 1; k1 < N1; ++k1) x[k1] = O::mul_tw(x[k1], tw[k1], m);
         const bufrsrc_t rout = make_buf(a.out[op] + (size_t)by * a.out_stride, a.out_len * 4u);
@@ -171,25 +172,25 @@ static bool walk_prefetch()
     return !(e && e[0] == '0');
 }
 
-template <class MM, bool LAZY, int LOGN1>
+template <class MM, bool LAZY, int LOGN1, bool WIDE = false>
 static void launch_col_t(bool inverse, bool half_in, const ColArgs<MM> &a, const ModParams &mp,
                          dim3 grid, hipStream_t s)
 {
     if constexpr (LOGN1 >= 5) {
         if (!inverse && half_in && a.loop_batch && !a.twist && !a.canon && walk_prefetch()) {
-            hipLaunchKernelGGL((col_walk_prefetch_kernel<MM, LAZY, LOGN1>), grid, dim3(256), 0, s, a, mp);
+            hipLaunchKernelGGL((col_walk_prefetch_kernel<MM, LAZY, LOGN1, WIDE>), grid, dim3(256), 0, s, a, mp);
             return;
         }
     }
     if (inverse)
         hipLaunchKernelGGL((col_kernel<MM, LAZY, LOGN1, true, false>), grid, dim3(256), 0, s, a, mp);
     else if (half_in)
-        hipLaunchKernelGGL((col_kernel<MM, LAZY, LOGN1, false, true>), grid, dim3(256), 0, s, a, mp);
+        hipLaunchKernelGGL((col_kernel<MM, LAZY, LOGN1, false, true, false, WIDE>), grid, dim3(256), 0, s, a, mp);
     else
-        hipLaunchKernelGGL((col_kernel<MM, LAZY, LOGN1, false, false>), grid, dim3(256), 0, s, a, mp);
+        hipLaunchKernelGGL((col_kernel<MM, LAZY, LOGN1, false, false, false, WIDE>), grid, dim3(256), 0, s, a, mp);
 }
 
-template <class MM, bool LAZY>
+template <class MM, bool LAZY, bool WIDE = false>
 static void launch_col_l(int logN1, bool inverse, bool half_in, const ColArgs<MM> &a,
                          const ModParams &mp, dim3 grid, hipStream_t s)
 {
@@ -197,9 +198,9 @@ static void launch_col_l(int logN1, bool inverse, bool half_in, const ColArgs<MM
     case 1: launch_col_t<MM, LAZY, 1>(inverse, half_in, a, mp, grid, s); break;
     case 2: launch_col_t<MM, LAZY, 2>(inverse, half_in, a, mp, grid, s); break;
     case 3: launch_col_t<MM, LAZY, 3>(inverse, half_in, a, mp, grid, s); break;
-    case 4: launch_col_t<MM, LAZY, 4>(inverse, half_in, a, mp, grid, s); break;
-    case 5: launch_col_t<MM, LAZY, 5>(inverse, half_in, a, mp, grid, s); break;
-    case 6: launch_col_t<MM, LAZY, 6>(inverse, half_in, a, mp, grid, s); break;
+    case 4: launch_col_t<MM, LAZY, 4, WIDE>(inverse, half_in, a, mp, grid, s); break;      // the wide-range transform pays
+    case 5: launch_col_t<MM, LAZY, 5, WIDE>(inverse, half_in, a, mp, grid, s); break;      // from 16 points up
+    case 6: launch_col_t<MM, LAZY, 6, WIDE>(inverse, half_in, a, mp, grid, s); break;
     default: note_unsupported_launch("col_kernel: no instantiation for log2(N1) =", logN1); break;
     }
 }
@@ -227,7 +228,7 @@ bool launch_col_u64in(bool lazy, int logN1, const void *args, const ModParams &m
     return true;
 }
 
-void launch_col(int kind, bool lazy, int logN1, bool inverse, bool half_in, const void *args,
+void launch_col(int kind, int lazy, int logN1, bool inverse, bool half_in, const void *args,
                 const ModParams &mp, unsigned cols_per_row, unsigned batch, unsigned nops,
                 hipStream_t s)
 {
@@ -242,12 +243,14 @@ void launch_col(int kind, bool lazy, int logN1, bool inverse, bool half_in, cons
     if (kind == 0) {
         auto a = *static_cast<const ColArgs<Mont32> *>(args);
         a.loop_batch = walk ? batch : 0;
-        if (lazy) launch_col_l<Mont32, true>(logN1, inverse, half_in, a, mp, grid, s);
+        if (lazy == 2 && !inverse) launch_col_l<Mont32, true, true>(logN1, inverse, half_in, a, mp, grid, s);
+        else if (lazy) launch_col_l<Mont32, true>(logN1, inverse, half_in, a, mp, grid, s);
         else launch_col_l<Mont32, false>(logN1, inverse, half_in, a, mp, grid, s);
     } else {
         auto a = *static_cast<const ColArgs<Barrett32> *>(args);
         a.loop_batch = walk ? batch : 0;
-        if (lazy) launch_col_l<Barrett32, true>(logN1, inverse, half_in, a, mp, grid, s);
+        if (lazy == 2 && !inverse) launch_col_l<Barrett32, true, true>(logN1, inverse, half_in, a, mp, grid, s);
+        else if (lazy) launch_col_l<Barrett32, true>(logN1, inverse, half_in, a, mp, grid, s);
         else launch_col_l<Barrett32, false>(logN1, inverse, half_in, a, mp, grid, s);
     }
 }

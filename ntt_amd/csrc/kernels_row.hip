@@ -19,16 +19,16 @@
 
 namespace ntt {
 
-template <class MM, bool LAZY>
+template <class MM, bool LAZY, bool WIDE = false>
 __global__ void __launch_bounds__(256) row_mul_kernel(const RowArgs<MM> a, const ModParams m)
 {
     __shared__ uint32_t lds[kLdsWords];
-    row_mul_body<MM, LAZY>(a, m, lds, blockIdx.x);
+    row_mul_body<MM, LAZY, WIDE>(a, m, lds, blockIdx.x);
 }
 
 // Whole product of one pair when L = 4096: the row kernel with the padding, twist, scale and output cut
 // that the column passes do for longer transforms (3-4x faster than radix-2 stages in LDS, small_kernel).
-template <class MM, bool LAZY>
+template <class MM, bool LAZY, bool WIDE = false>
 __global__ void __launch_bounds__(256) row_product_kernel(const Row4096Args<MM> a, const ModParams m)
 {
     using O = Ops<MM, LAZY>;
@@ -51,11 +51,11 @@ __global__ void __launch_bounds__(256) row_product_kernel(const Row4096Args<MM> 
             xb[j] = O::mul_tw(xb[j], w, m);
         }
     }
-    row_forward<MM, LAZY>(xa, lds, t, a.row, m);
-    row_forward<MM, LAZY>(xb, lds, t, a.row, m);
+    row_forward<MM, LAZY, WIDE>(xa, lds, t, a.row, m);
+    row_forward<MM, LAZY, WIDE>(xb, lds, t, a.row, m);
 #pragma unroll
     for (int k = 0; k < 16; ++k) xa[k] = O::mul(xa[k], xb[k], m);
-    row_inverse<MM, LAZY>(xa, lds, t, a.row, m);              // loose outputs, unscaled
+    row_inverse<MM, LAZY, WIDE>(xa, lds, t, a.row, m);        // loose outputs, unscaled
     uint32_t *__restrict__ po = a.row.out + (size_t)blockIdx.x * a.out_stride;
     if (a.fold) {                                             // x^2048 + 1: position i + 2048 sits in the same thread (uniform)
 #pragma unroll
@@ -75,21 +75,23 @@ __global__ void __launch_bounds__(256) row_product_kernel(const Row4096Args<MM> 
     }
 }
 
-void launch_row_product(int kind, bool lazy, const void *args, const ModParams &mp, unsigned batch, hipStream_t s)
+void launch_row_product(int kind, int lazy, const void *args, const ModParams &mp, unsigned batch, hipStream_t s)
 {
     if (kind == 0) {
         const auto &a = *static_cast<const Row4096Args<Mont32> *>(args);
-        if (lazy) hipLaunchKernelGGL((row_product_kernel<Mont32, true>), dim3(batch), dim3(256), 0, s, a, mp);
+        if (lazy == 2) hipLaunchKernelGGL((row_product_kernel<Mont32, true, true>), dim3(batch), dim3(256), 0, s, a, mp);
+        else if (lazy) hipLaunchKernelGGL((row_product_kernel<Mont32, true>), dim3(batch), dim3(256), 0, s, a, mp);
         else hipLaunchKernelGGL((row_product_kernel<Mont32, false>), dim3(batch), dim3(256), 0, s, a, mp);
     } else {
         const auto &a = *static_cast<const Row4096Args<Barrett32> *>(args);
-        if (lazy) hipLaunchKernelGGL((row_product_kernel<Barrett32, true>), dim3(batch), dim3(256), 0, s, a, mp);
+        if (lazy == 2) hipLaunchKernelGGL((row_product_kernel<Barrett32, true, true>), dim3(batch), dim3(256), 0, s, a, mp);
+        else if (lazy) hipLaunchKernelGGL((row_product_kernel<Barrett32, true>), dim3(batch), dim3(256), 0, s, a, mp);
         else hipLaunchKernelGGL((row_product_kernel<Barrett32, false>), dim3(batch), dim3(256), 0, s, a, mp);
     }
 }
 
 // Forward only: natural row in, digit-reversed spectrum out (position 16*t + k).
-template <class MM, bool LAZY>
+template <class MM, bool LAZY, bool WIDE = false>
 __global__ void __launch_bounds__(256) row_fwd_kernel(const RowArgs<MM> a, const ModParams m)
 {
     __shared__ uint32_t lds[kLdsWords];
@@ -99,7 +101,7 @@ __global__ void __launch_bounds__(256) row_fwd_kernel(const RowArgs<MM> a, const
     uint32_t x[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) x[j] = pa[t + 256 * j];
-    row_forward<MM, LAZY>(x, lds, t, a, m);
+    row_forward<MM, LAZY, WIDE>(x, lds, t, a, m);
     uint4 *__restrict__ po = reinterpret_cast<uint4 *>(a.out + row + 16 * t);
 #pragma unroll
     for (int q = 0; q < 4; ++q) po[q] = make_uint4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
@@ -107,7 +109,7 @@ __global__ void __launch_bounds__(256) row_fwd_kernel(const RowArgs<MM> a, const
 
 // Inverse only: digit-reversed spectrum in, natural row out (unscaled; the column pass or the
 // caller's scale twiddle finishes it).
-template <class MM, bool LAZY>
+template <class MM, bool LAZY, bool WIDE = false>
 __global__ void __launch_bounds__(256) row_inv_kernel(const RowArgs<MM> a, const ModParams m)
 {
     __shared__ uint32_t lds[kLdsWords];
@@ -120,59 +122,63 @@ __global__ void __launch_bounds__(256) row_inv_kernel(const RowArgs<MM> a, const
         const uint4 v = pa[q];
         x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
     }
-    row_inverse<MM, LAZY>(x, lds, t, a, m);
+    row_inverse<MM, LAZY, WIDE>(x, lds, t, a, m);
     uint32_t *__restrict__ po = a.out + row;
 #pragma unroll
     for (int j = 0; j < 16; ++j) po[t + 256 * j] = x[j];
 }
 
-template <int WHICH, class MM, bool LAZY>
+template <int WHICH, class MM, bool LAZY, bool WIDE = false>
 static void launch_row_t(const RowArgs<MM> &a, const ModParams &mp, unsigned rows, hipStream_t s)
 {
-    if (WHICH == 0) hipLaunchKernelGGL((row_mul_kernel<MM, LAZY>), dim3(rows), dim3(256), 0, s, a, mp);
-    if (WHICH == 1) hipLaunchKernelGGL((row_fwd_kernel<MM, LAZY>), dim3(rows), dim3(256), 0, s, a, mp);
-    if (WHICH == 2) hipLaunchKernelGGL((row_inv_kernel<MM, LAZY>), dim3(rows), dim3(256), 0, s, a, mp);
+    if (WHICH == 0) hipLaunchKernelGGL((row_mul_kernel<MM, LAZY, WIDE>), dim3(rows), dim3(256), 0, s, a, mp);
+    if (WHICH == 1) hipLaunchKernelGGL((row_fwd_kernel<MM, LAZY, WIDE>), dim3(rows), dim3(256), 0, s, a, mp);
+    if (WHICH == 2) hipLaunchKernelGGL((row_inv_kernel<MM, LAZY, WIDE>), dim3(rows), dim3(256), 0, s, a, mp);
 }
 
+// lazy: 0 strict [0, p), 1 lazy [0, 2p), 2 lazy with the wide-range transforms (p < 2^29)
 template <int WHICH>
-static void launch_row_any(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows,
+static void launch_row_any(int kind, int lazy, const void *args, const ModParams &mp, unsigned rows,
                            hipStream_t s)
 {
     if (kind == 0) {
         const auto &a = *static_cast<const RowArgs<Mont32> *>(args);
-        if (lazy) launch_row_t<WHICH, Mont32, true>(a, mp, rows, s);
+        if (lazy == 2) launch_row_t<WHICH, Mont32, true, true>(a, mp, rows, s);
+        else if (lazy) launch_row_t<WHICH, Mont32, true>(a, mp, rows, s);
         else launch_row_t<WHICH, Mont32, false>(a, mp, rows, s);
     } else {
         const auto &a = *static_cast<const RowArgs<Barrett32> *>(args);
-        if (lazy) launch_row_t<WHICH, Barrett32, true>(a, mp, rows, s);
+        if (lazy == 2) launch_row_t<WHICH, Barrett32, true, true>(a, mp, rows, s);
+        else if (lazy) launch_row_t<WHICH, Barrett32, true>(a, mp, rows, s);
         else launch_row_t<WHICH, Barrett32, false>(a, mp, rows, s);
     }
 }
 
 template <class MM>
-static void launch_row_mul_ext(bool lazy, const RowArgs<MM> &a, const ModParams &mp, unsigned rows, hipStream_t s,
+static void launch_row_mul_ext(int lazy, const RowArgs<MM> &a, const ModParams &mp, unsigned rows, hipStream_t s,
                                hipEvent_t e0, hipEvent_t e1)
 {
-    if (lazy) hipExtLaunchKernelGGL((row_mul_kernel<MM, true>), dim3(rows), dim3(256), 0, s, e0, e1, 0, a, mp);
+    if (lazy == 2) hipExtLaunchKernelGGL((row_mul_kernel<MM, true, true>), dim3(rows), dim3(256), 0, s, e0, e1, 0, a, mp);
+    else if (lazy) hipExtLaunchKernelGGL((row_mul_kernel<MM, true>), dim3(rows), dim3(256), 0, s, e0, e1, 0, a, mp);
     else hipExtLaunchKernelGGL((row_mul_kernel<MM, false>), dim3(rows), dim3(256), 0, s, e0, e1, 0, a, mp);
 }
 
-void launch_row_mul_timed(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s,
+void launch_row_mul_timed(int kind, int lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s,
                           hipEvent_t start, hipEvent_t stop)
 {
     if (kind == 0) launch_row_mul_ext<Mont32>(lazy, *static_cast<const RowArgs<Mont32> *>(args), mp, rows, s, start, stop);
     else launch_row_mul_ext<Barrett32>(lazy, *static_cast<const RowArgs<Barrett32> *>(args), mp, rows, s, start, stop);
 }
 
-void launch_row_mul(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s)
+void launch_row_mul(int kind, int lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s)
 {
     launch_row_any<0>(kind, lazy, args, mp, rows, s);
 }
-void launch_row_fwd(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s)
+void launch_row_fwd(int kind, int lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s)
 {
     launch_row_any<1>(kind, lazy, args, mp, rows, s);
 }
-void launch_row_inv(int kind, bool lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s)
+void launch_row_inv(int kind, int lazy, const void *args, const ModParams &mp, unsigned rows, hipStream_t s)
 {
     launch_row_any<2>(kind, lazy, args, mp, rows, s);
 }

@@ -27,6 +27,8 @@
 #include <memory>
 #include <thread>
 
+#include <dlfcn.h>
+
 #include "../../include/ntt_amd.h"
 #include "engine.hpp"
 
@@ -38,6 +40,57 @@
     } while (0)
 
 namespace ntt {
+
+// ---- RCCL, loaded on demand (transport "rccl" of the split transform) ----------------------------------------------------
+// The library does not link librccl: a Python process that also runs torch.distributed already holds torch's own copy,
+// and every default path here is plain HIP.  Only NTT_AMD_DIST_TRANSPORT=rccl opens it (dlopen, local symbols) and uses
+// the six calls below -- the grouped ncclSend / ncclRecv form of an all-to-all, one communicator per slot in this one
+// process (ncclCommInitAll), each pair of calls on the slot's own exchange stream.
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t stream) = nullptr;
+    int (*Recv)(void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t stream) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    static constexpr int kUint32 = 3;                    // ncclUint32 (rccl.h)
+};
+static Rccl *rccl_load()
+{
+    static std::mutex mu;
+    static Rccl r;
+    static bool tried = false;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!tried) {
+        tried = true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        if (r.lib) {
+            auto sym = [&](const char *n) { return dlsym(r.lib, n); };
+            r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+            r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+            r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+            r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+            r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+            r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+            r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+            if (!r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv || !r.GetErrorString) {
+                dlclose(r.lib);
+                r.lib = nullptr;
+            }
+        }
+    }
+    return r.lib ? &r : nullptr;
+}
+#define RCCL_TRY(R, expr)                                                                                          \
+    do {                                                                                                           \
+        const int e_ = (expr);                                                                                     \
+        if (e_ != 0) return ntt::fail(NTT_ERR_HIP, std::string(#expr) + ": " + (R)->GetErrorString(e_));           \
+    } while (0)
 
 struct GroupCrt {
     int n = 0;
@@ -390,6 +443,10 @@ void group_dist_plan_release(ntt_dist_plan *dp)
         gs.held.release(); gs.sendbuf.release(); gs.rowbuf.release();
     }
     dp->gslot.clear();
+    if (!dp->comms.empty())
+        if (Rccl *r = rccl_load())
+            for (void *c : dp->comms) if (c) (void)r->CommDestroy(c);
+    dp->comms.clear();
     for (ntt_dist_plan *q : dp->part) ntt_dist_plan_destroy(q);
     dp->part.clear();
 }
@@ -423,7 +480,8 @@ int group_dist_plan_create(ntt_ctx *g, uint32_t p, int lgL, int world, int kind,
         if (t == "p2p") dp->transport = 0;
         else if (t == "copyin") dp->transport = 1;
         else if (t == "copy") dp->transport = 2;
-        else return fail(NTT_ERR_INVALID, "NTT_AMD_DIST_TRANSPORT must be p2p, copyin or copy");
+        else if (t == "rccl") dp->transport = 3;
+        else return fail(NTT_ERR_INVALID, "NTT_AMD_DIST_TRANSPORT must be p2p, copyin, copy or rccl");
         if (dp->transport < 2 && !g->peer_ok)
             return fail(NTT_ERR_UNSUPPORTED, "NTT_AMD_DIST_TRANSPORT=" + t + " needs peer access between the devices of the context");
     }
@@ -439,10 +497,10 @@ int group_dist_plan_create(ntt_ctx *g, uint32_t p, int lgL, int world, int kind,
         HIP_TRY(hipSetDevice(g->sub[(size_t)s]->device));
         int rc = gs.rowbuf.ensure(bytes);
         if (!rc && dp->transport >= 1) rc = gs.held.ensure(bytes);
-        if (!rc && dp->transport == 2) rc = gs.sendbuf.ensure(bytes);
+        if (!rc && dp->transport >= 2) rc = gs.sendbuf.ensure(bytes);
         if (rc) return rc;
         if (dp->transport >= 1) HIP_TRY(hipStreamCreateWithFlags(&gs.copy_in, hipStreamNonBlocking));
-        if (dp->transport == 2) HIP_TRY(hipStreamCreateWithFlags(&gs.copy_out, hipStreamNonBlocking));
+        if (dp->transport >= 2) HIP_TRY(hipStreamCreateWithFlags(&gs.copy_out, hipStreamNonBlocking));
         for (hipEvent_t *e : {&gs.start, &gs.ready, &gs.done, &gs.fin, &gs.out_done})
             HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
         gs.ev_in.assign((size_t)dp->chunks, nullptr);
@@ -450,6 +508,20 @@ int group_dist_plan_create(ntt_ctx *g, uint32_t p, int lgL, int world, int kind,
         for (int c = 0; c < dp->chunks; ++c) {
             HIP_TRY(hipEventCreateWithFlags(&gs.ev_in[(size_t)c], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&gs.ev_k[(size_t)c], hipEventDisableTiming));
+        }
+    }
+    if (dp->transport == 3) {
+        // one RCCL communicator per slot, all in this process.  RCCL wants distinct devices: a one-GPU rehearsal with
+        // repeated ids is refused here (NTT_ERR_UNSUPPORTED with RCCL's own message) -- this transport has never moved data
+        Rccl *r = rccl_load();
+        if (!r) return fail(NTT_ERR_UNSUPPORTED, "NTT_AMD_DIST_TRANSPORT=rccl: librccl.so could not be loaded");
+        std::vector<int> devs;
+        for (ntt_ctx *c : g->sub) devs.push_back(c->device);
+        dp->comms.assign((size_t)world, nullptr);
+        const int e = r->CommInitAll(dp->comms.data(), world, devs.data());
+        if (e != 0) {
+            dp->comms.clear();
+            return fail(NTT_ERR_UNSUPPORTED, std::string("NTT_AMD_DIST_TRANSPORT=rccl: ncclCommInitAll: ") + r->GetErrorString(e));
         }
     }
     undo.armed = false;
@@ -511,7 +583,10 @@ static int group_dist_run(ntt_dist_plan *dp, const uint32_t *const *in, uint32_t
     } else {
         for (int r = 0; r < G; ++r) rows[(size_t)r] = in[r];
     }
-    // the column pass of every slot, exchanges included
+    // the column pass of every slot, exchanges included, one column chunk after the other: the exchange of chunk c + 1
+    // (copy / RCCL streams) runs beside the kernel of chunk c (the slot's compute stream)
+    Rccl *rc_lib = dp->transport == 3 ? rccl_load() : nullptr;
+    if (dp->transport == 3 && !rc_lib) return fail(NTT_ERR_INTERNAL, "RCCL transport without librccl");
     for (int h = 0; h < G; ++h) {
         ntt_ctx *c = g->sub[(size_t)h];
         auto &gs = dp->gslot[(size_t)h];
@@ -520,43 +595,82 @@ static int group_dist_run(ntt_dist_plan *dp, const uint32_t *const *in, uint32_t
         if (inverse)
             for (int r = 0; r < G; ++r)
                 if (r != h) HIP_TRY(hipStreamWaitEvent(sh, dp->gslot[(size_t)r].ready, 0));
-        if (dp->transport >= 1) {                           // copies run on a stream of their own, behind everything queued so far
+        if (dp->transport >= 1) {                           // exchanges run on streams of their own, behind everything queued so far
             HIP_TRY(hipEventRecord(gs.start, sh));
             HIP_TRY(hipStreamWaitEvent(gs.copy_in, gs.start, 0));
             if (gs.copy_out) HIP_TRY(hipStreamWaitEvent(gs.copy_out, gs.start, 0));
         }
-        uint32_t *held = static_cast<uint32_t *>(gs.held.ptr), *sendbuf = static_cast<uint32_t *>(gs.sendbuf.ptr);
-        const uint32_t *src[kMaxDistWorld];
-        uint32_t *dst[kMaxDistWorld];
-        for (int i = 0; i < G; ++i) {
-            src[i] = dp->transport == 0 ? rows[(size_t)i] + (size_t)h * cols : held + (size_t)i * cols;
-            dst[i] = dp->transport == 2 ? sendbuf + (size_t)i * cols : out[i] + (size_t)h * cols;
+    }
+    for (int ch = 0; ch < C; ++ch) {
+        const uint32_t c0 = (uint32_t)ch * cc;
+        if (dp->transport == 3) {                           // exchange in: grouped send / recv, every slot's slice of every row
+            RCCL_TRY(rc_lib, rc_lib->GroupStart());
+            for (int h = 0; h < G; ++h) {
+                auto &gs = dp->gslot[(size_t)h];
+                HIP_TRY(hipSetDevice(g->sub[(size_t)h]->device));
+                uint32_t *held = static_cast<uint32_t *>(gs.held.ptr);
+                for (int i = 0; i < G; ++i) {
+                    RCCL_TRY(rc_lib, rc_lib->Send(rows[(size_t)h] + (size_t)i * cols + c0, cc, Rccl::kUint32, i, dp->comms[(size_t)h], gs.copy_in));
+                    RCCL_TRY(rc_lib, rc_lib->Recv(held + (size_t)i * cols + c0, cc, Rccl::kUint32, i, dp->comms[(size_t)h], gs.copy_in));
+                }
+            }
+            RCCL_TRY(rc_lib, rc_lib->GroupEnd());
         }
-        for (int ch = 0; ch < C; ++ch) {
-            const uint32_t c0 = (uint32_t)ch * cc;
-            if (dp->transport >= 1) {                       // exchange in: this chunk's slice of every peer's row
+        for (int h = 0; h < G; ++h) {
+            ntt_ctx *c = g->sub[(size_t)h];
+            auto &gs = dp->gslot[(size_t)h];
+            HIP_TRY(hipSetDevice(c->device));
+            hipStream_t sh = c->stream;
+            uint32_t *held = static_cast<uint32_t *>(gs.held.ptr), *sendbuf = static_cast<uint32_t *>(gs.sendbuf.ptr);
+            const uint32_t *src[kMaxDistWorld];
+            uint32_t *dst[kMaxDistWorld];
+            for (int i = 0; i < G; ++i) {
+                src[i] = dp->transport == 0 ? rows[(size_t)i] + (size_t)h * cols : held + (size_t)i * cols;
+                dst[i] = dp->transport >= 2 ? sendbuf + (size_t)i * cols : out[i] + (size_t)h * cols;
+            }
+            if (dp->transport == 1 || dp->transport == 2)   // exchange in: this chunk's slice of every peer's row
                 for (int i = 0; i < G; ++i)
                     HIP_TRY(hipMemcpyPeerAsync(held + (size_t)i * cols + c0, c->device, rows[(size_t)i] + (size_t)h * cols + c0,
                                                g->sub[(size_t)i]->device, (size_t)cc * sizeof(uint32_t), gs.copy_in));
+            if (dp->transport >= 1) {
                 HIP_TRY(hipEventRecord(gs.ev_in[(size_t)ch], gs.copy_in));
                 HIP_TRY(hipStreamWaitEvent(sh, gs.ev_in[(size_t)ch], 0));
             }
             const int rc = kind == NTT_MODMUL_MONTGOMERY ? launch_slot_colpass<Mont32>(dp, h, inverse, src, dst, c0, cc, sh)
                                                          : launch_slot_colpass<Barrett32>(dp, h, inverse, src, dst, c0, cc, sh);
             if (rc) return rc;
-            if (dp->transport == 2) {                       // exchange out: row k1 of this chunk to slot k1
+            if (dp->transport >= 2) {                       // exchange out: row k1 of this chunk to slot k1
                 HIP_TRY(hipEventRecord(gs.ev_k[(size_t)ch], sh));
                 HIP_TRY(hipStreamWaitEvent(gs.copy_out, gs.ev_k[(size_t)ch], 0));
+            }
+            if (dp->transport == 2)
                 for (int i = 0; i < G; ++i)
                     HIP_TRY(hipMemcpyPeerAsync(out[i] + (size_t)h * cols + c0, g->sub[(size_t)i]->device, sendbuf + (size_t)i * cols + c0,
                                                c->device, (size_t)cc * sizeof(uint32_t), gs.copy_out));
+        }
+        if (dp->transport == 3) {
+            RCCL_TRY(rc_lib, rc_lib->GroupStart());
+            for (int h = 0; h < G; ++h) {
+                auto &gs = dp->gslot[(size_t)h];
+                HIP_TRY(hipSetDevice(g->sub[(size_t)h]->device));
+                const uint32_t *sendbuf = static_cast<const uint32_t *>(gs.sendbuf.ptr);
+                for (int i = 0; i < G; ++i) {
+                    RCCL_TRY(rc_lib, rc_lib->Send(sendbuf + (size_t)i * cols + c0, cc, Rccl::kUint32, i, dp->comms[(size_t)h], gs.copy_out));
+                    RCCL_TRY(rc_lib, rc_lib->Recv(out[h] + (size_t)i * cols + c0, cc, Rccl::kUint32, i, dp->comms[(size_t)h], gs.copy_out));
+                }
             }
+            RCCL_TRY(rc_lib, rc_lib->GroupEnd());
         }
-        if (dp->transport == 2) {
+    }
+    for (int h = 0; h < G; ++h) {
+        ntt_ctx *c = g->sub[(size_t)h];
+        auto &gs = dp->gslot[(size_t)h];
+        HIP_TRY(hipSetDevice(c->device));
+        if (dp->transport >= 2) {
             HIP_TRY(hipEventRecord(gs.out_done, gs.copy_out));
-            HIP_TRY(hipStreamWaitEvent(sh, gs.out_done, 0));
+            HIP_TRY(hipStreamWaitEvent(c->stream, gs.out_done, 0));
         }
-        HIP_TRY(hipEventRecord(gs.done, sh));
+        HIP_TRY(hipEventRecord(gs.done, c->stream));
     }
     HIP_TRY(hipGetLastError());
     // every slot waits for the rows its peers sent; forward: then its local S-point transform, in place in out[r]

@@ -32,14 +32,22 @@ constexpr int kLdsWords = kRowLen + kRowLen / 16;      // 4352 dwords = 17 KiB
 __device__ __forceinline__ uint32_t P1(uint32_t i) { return i + ((i >> 8) << 4); }
 __device__ __forceinline__ uint32_t P2(uint32_t i) { return i + (i >> 4); }
 
+// WIDE (p < 2^29, device_ntt.hpp): the loose 16-point transforms keep sums unreduced up to 4p and hand out values below
+// 8p; what is not multiplied next is brought back below 2p (tighten_wide).  Inputs are below 2p as always.
+template <bool WIDE>
+__device__ __forceinline__ uint32_t row_tighten(uint32_t x, const ModParams &m, uint32_t bound)
+{
+    return WIDE ? tighten_wide(x, m) : csub(x, bound);
+}
+
 // x[j] = row[t + 256*j] on entry; on exit x[k] = spectrum at position 16*t + k.
-template <class MM, bool LAZY>
+template <class MM, bool LAZY, bool WIDE = false>
 __device__ __forceinline__ void row_forward(uint32_t (&x)[16], uint32_t *lds, const uint32_t t,
                                             const RowArgs<MM> &a, const ModParams &m)
 {
     using O = Ops<MM, LAZY>;
-    reg_ntt<MM, LAZY, 4, false, true>(x, a.roots, m);            // loose: 15 of 16 outputs are multiplied next
-    x[0] = O::tighten(x[0], m);
+    reg_ntt<MM, LAZY, 4, false, true, WIDE>(x, a.roots, m);      // loose: 15 of 16 outputs are multiplied next
+    x[0] = row_tighten<WIDE>(x[0], m, O::bound(m));
 #pragma unroll
     for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], NTT_TW(a.twA, k * 256 + t), m);
 #pragma unroll
@@ -49,8 +57,8 @@ __device__ __forceinline__ void row_forward(uint32_t (&x)[16], uint32_t *lds, co
 #pragma unroll
     for (int j = 0; j < 16; ++j) NTT_LDS_LD(x[j], P1(b * 256 + j * 16 + i));
     NTT_BARRIER();
-    reg_ntt<MM, LAZY, 4, false, true>(x, a.roots, m);
-    x[0] = O::tighten(x[0], m);
+    reg_ntt<MM, LAZY, 4, false, true, WIDE>(x, a.roots, m);
+    x[0] = row_tighten<WIDE>(x[0], m, O::bound(m));
 #pragma unroll
     for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], NTT_TW(a.twB, k * 16 + i), m);
 #pragma unroll
@@ -63,12 +71,12 @@ __device__ __forceinline__ void row_forward(uint32_t (&x)[16], uint32_t *lds, co
 }
 
 // x[k] = spectrum at position 16*t + k on entry; on exit x[j] = row[t + 256*j] (unscaled).
-template <class MM, bool LAZY>
+template <class MM, bool LAZY, bool WIDE = false>
 __device__ __forceinline__ void row_inverse(uint32_t (&x)[16], uint32_t *lds, const uint32_t t,
                                             const RowArgs<MM> &a, const ModParams &m)
 {
     using O = Ops<MM, LAZY>;
-    reg_ntt<MM, LAZY, 4, false, true>(x, a.iroots, m);           // loose values travel through LDS
+    reg_ntt<MM, LAZY, 4, false, true, WIDE>(x, a.iroots, m);     // loose values travel through LDS
 #pragma unroll
     for (int j = 0; j < 16; ++j) NTT_LDS_ST(P2(t * 16 + j), x[j]);
     NTT_BARRIER();
@@ -76,26 +84,26 @@ __device__ __forceinline__ void row_inverse(uint32_t (&x)[16], uint32_t *lds, co
 #pragma unroll
     for (int k = 0; k < 16; ++k) NTT_LDS_LD(x[k], P2(b * 256 + k * 16 + i));
     NTT_BARRIER();
-    x[0] = O::tighten(x[0], m);
+    x[0] = row_tighten<WIDE>(x[0], m, O::bound(m));
 #pragma unroll
     for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], NTT_TW(a.itwB, k * 16 + i), m);
-    reg_ntt<MM, LAZY, 4, false, true>(x, a.iroots, m);
+    reg_ntt<MM, LAZY, 4, false, true, WIDE>(x, a.iroots, m);
 #pragma unroll
     for (int j = 0; j < 16; ++j) NTT_LDS_ST(P1(b * 256 + j * 16 + i), x[j]);
     NTT_BARRIER();
 #pragma unroll
     for (int k = 0; k < 16; ++k) NTT_LDS_LD(x[k], P1(k * 256 + t));
     NTT_BARRIER();
-    x[0] = O::tighten(x[0], m);
+    x[0] = row_tighten<WIDE>(x[0], m, O::bound(m));
 #pragma unroll
     for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], NTT_TW(a.itwA, k * 256 + t), m);
     // loose output: the innermost inverse column level multiplies every row (rows >= 1 by the
-    // 4-step twiddle, row 0 by the scale constant), so no reduction is needed here
-    reg_ntt<MM, LAZY, 4, false, true>(x, a.iroots, m);
+    // 4-step twiddle, row 0 by the scale constant), so no reduction is needed here (WIDE: below 8p, any u32 is fine there)
+    reg_ntt<MM, LAZY, 4, false, true, WIDE>(x, a.iroots, m);
 }
 
 // Fused multiply of one 4096-point row (forward a, forward b, pointwise, inverse).
-template <class MM, bool LAZY>
+template <class MM, bool LAZY, bool WIDE = false>
 __device__ __forceinline__ void row_mul_body(const RowArgs<MM> &a, const ModParams &m, uint32_t *lds,
                                              const uint32_t row_index)
 {
@@ -123,11 +131,11 @@ __device__ __forceinline__ void row_mul_body(const RowArgs<MM> &a, const ModPara
 #pragma unroll
     for (int j = 0; j < 16; ++j) xb[j] = pb[t + 256 * j];
 #endif
-    row_forward<MM, LAZY>(xa, lds, t, a, m);
-    row_forward<MM, LAZY>(xb, lds, t, a, m);
+    row_forward<MM, LAZY, WIDE>(xa, lds, t, a, m);
+    row_forward<MM, LAZY, WIDE>(xb, lds, t, a, m);
 #pragma unroll
     for (int k = 0; k < 16; ++k) xa[k] = O::mul(xa[k], xb[k], m);
-    row_inverse<MM, LAZY>(xa, lds, t, a, m);
+    row_inverse<MM, LAZY, WIDE>(xa, lds, t, a, m);
     uint32_t *__restrict__ po = a.out + row;
 #if defined(NTT_ABL_NODATA)
     uint32_t acc = 0;

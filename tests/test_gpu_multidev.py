@@ -288,3 +288,23 @@ def test_group_dist_transform_2pow26_over_8_slots(nt, monkeypatch, transport):
             acc = (acc + s * cur) % p
             cur = cur * step % p
         assert int(X[k % ndev][k // ndev].item()) == acc, k
+
+
+def test_group_dist_rccl_transport_is_refused_on_repeated_devices(nt, monkeypatch):
+    """NTT_AMD_DIST_TRANSPORT=rccl opens librccl (dlopen) and asks for one communicator per slot; RCCL needs distinct
+    devices, so the one-GPU rehearsal must get a clean NTT_ERR_UNSUPPORTED carrying RCCL's message -- and the context
+    must stay usable (the next plan takes the default transport).  The data path of this transport has never run."""
+    monkeypatch.setenv("NTT_AMD_DIST_TRANSPORT", "rccl")
+    g = nt.Context(devices=[0, 0])
+    with pytest.raises(nt.NttError) as e:
+        nt.DistPlan(g, 469762049, 18, 2, 0)
+    assert e.value.code == nt.ERR_UNSUPPORTED and ("ncclCommInitAll" in str(e.value) or "librccl" in str(e.value)), str(e.value)
+    monkeypatch.setenv("NTT_AMD_DIST_TRANSPORT", "bogus")
+    with pytest.raises(nt.NttError) as e:
+        nt.DistPlan(g, 469762049, 18, 2, 0)
+    assert e.value.code == nt.ERR_INVALID
+    monkeypatch.delenv("NTT_AMD_DIST_TRANSPORT")
+    dp = nt.DistPlan(g, 469762049, 18, 2, 0)
+    assert dp.transport[0] == "p2p"
+    dp.close()
+    g.close()

@@ -219,3 +219,62 @@ def test_forward_column_pass_prefetch_variant(nt, monkeypatch, n):
         got = outs[0].cpu().numpy().view(np.uint32)
         for r in (0, 16, 17, 33, batch - 1):                # first, second and third product of a workgroup's walk
             assert np.array_equal(got[r], orc.poly_multiply(a[r], b[r], p, kind="barrett")), (p, kind, r)
+
+
+def _largest_prime_below(limit, two_adicity):
+    """The largest prime p < limit with 2^two_adicity | p - 1 (trial division: limit is 2^29 here)."""
+    step = 1 << two_adicity
+    p = (limit - 2) // step * step + 1
+    while p > step:
+        if all(p % q for q in range(3, int(p ** 0.5) + 1, 2)):
+            return p
+        p -= step
+    raise AssertionError("no such prime")
+
+
+@pytest.mark.parametrize("n,batch", [(2048, 3), (5000, 2), (40000, 20), (131072, 1), (131072, 19)])
+def test_wide_range_kernels_for_primes_below_2pow29(nt, monkeypatch, n, batch):
+    """p < 2^29 (8p <= 2^32): the row kernels and forward register column passes keep sums unreduced up to 4p and hand
+    out values below 8p (device_ntt.hpp, WIDE; NTT_AMD_WIDE=0 keeps the [0, 2p) kernels).  The reference's three shipped
+    primes (main-montgomery.cc:301-306) and the largest prime below 2^29 with 2^18 | p - 1 (the tightest ranges), operands
+    of all p - 1 in the first row, Montgomery and Barrett: identical to the [0, 2p) kernels, rows against the oracle
+    (generator 3 is the reference's; for the fourth prime the evaluation identity stands in)."""
+    import torch
+    from test_gpu_full_configs import _check_rows
+    tight = _largest_prime_below(1 << 29, 18)
+    assert tight > (1 << 29) - (1 << 24)
+    for p in (7340033, 104857601, 469762049, tight):
+        if (p - 1) % (1 << (2 * n - 1).bit_length()) != 0:
+            continue                                         # 7340033 = 7 * 2^20 + 1 serves L <= 2^20: every size here
+        for kind in (nt.MONTGOMERY, nt.BARRETT):
+            rng = np.random.default_rng(n + batch + p % 997 + kind)
+            a = rng.integers(0, p, size=(batch, n), dtype=np.int64).astype(np.uint32)
+            b = rng.integers(0, p, size=(batch, n), dtype=np.int64).astype(np.uint32)
+            a[0, :] = p - 1
+            b[0, :] = p - 1
+            da, db = torch.from_numpy(a.view(np.int32)).cuda(), torch.from_numpy(b.view(np.int32)).cuda()
+            outs = []
+            for flag in ("1", "0"):
+                monkeypatch.setenv("NTT_AMD_WIDE", flag)        # read when the plan is created
+                c = nt.Context(0)
+                plan = c.plan(p, n, batch, kind)
+                out = torch.full((batch, 2 * n - 1), -1, dtype=torch.int32, device="cuda")
+                plan.multiply(da, db, out=out, batch=batch)
+                c.synchronize()
+                outs.append(out)
+                if flag == "1" and n == 5000:                   # the natural-order transforms use the same row kernels
+                    x = rng.integers(0, p, size=plan.length, dtype=np.int64).astype(np.uint32)
+                    y = x.copy()
+                    plan.forward(y, 1)
+                    if p != tight:
+                        assert np.array_equal(y, orc.ntt(x, p)), p
+                    plan.inverse(y, 1)
+                    assert np.array_equal(y, x), p
+                plan.close()
+                c.close()
+            assert torch.equal(outs[0], outs[1]), (p, kind)
+            _check_rows(da, db, outs[0], 2 * n - 1, p, torch, rng)
+            if p != tight:
+                got = outs[0].cpu().numpy().view(np.uint32)
+                for r in sorted({0, batch - 1}):
+                    assert np.array_equal(got[r], orc.poly_multiply(a[r], b[r], p, kind="barrett")), (p, kind, r)
