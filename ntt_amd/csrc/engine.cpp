@@ -4,7 +4,6 @@
 #include "engine.hpp"
 
 #include <algorithm>
-#include <chrono>
 #include <exception>
 #include <new>
 #include <cstdio>
@@ -87,23 +86,11 @@ int take_launch_error()
             return ntt::fail(NTT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));  \
     } while (0)
 
-// Wait for the context's stream.  The harness calls one product and waits for it (main-montgomery.cc:336-346): there the
-// wake-up of a blocked host thread is a large part of what it measures (14 us for the n = 4 case whose kernel runs 3 us), so
-// the wait first polls the stream for up to NTT_AMD_SYNC_SPIN_US microseconds (default 200; 0 = block at once) and only
-// then blocks in hipStreamSynchronize.
+// Wait for the context's stream.  (Round 3 tried polling hipStreamQuery for a while before blocking, to shorten the
+// harness's one-product-and-wait loop, main-montgomery.cc:336-346: every query costs microseconds of its own and the
+// n = 4 case went from 13.6 to 30 us -- hipStreamSynchronize already waits actively; profiles/latency_r03.txt.)
 int sync_stream(ntt_ctx *cx)
 {
-    static const long spin_us = [] { const char *e = std::getenv("NTT_AMD_SYNC_SPIN_US"); return e ? std::atol(e) : 200L; }();
-    if (spin_us > 0) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (;;) {
-            const hipError_t e = hipStreamQuery(cx->stream);
-            if (e == hipSuccess) return NTT_OK;
-            if (e != hipErrorNotReady) return fail(NTT_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e));
-            (void)hipGetLastError();                       // "not ready" is sticky in the runtime's last-error slot
-            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= spin_us) break;
-        }
-    }
     HIP_TRY(hipStreamSynchronize(cx->stream));
     return NTT_OK;
 }

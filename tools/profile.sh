@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 # default lanes (NTT_AMD_STREAMS unset): the trace then sees the same overlapped launches as bench.py
 cd /tmp
-BENCH="python3 $REPO/bench.py --no-cpu-baseline --no-one-lane --sustained-seconds 0"
+BENCH="python3 $REPO/bench.py --no-cpu-baseline --no-one-lane --no-also --sustained-seconds 0"
 
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH --steps 5 --warmup 2 \
     > "$OUT/trace.log" 2>&1 || { echo "kernel-trace pass failed"; tail -5 "$OUT/trace.log"; exit 1; }

@@ -20,6 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
+    if "col_walk_prefetch_kernel" in name:           # the walking first forward pass (round 3): the forward column kernel
+        return "col_kernel_fwd"
     for k in ("col16_kernel", "col_kernel", "row_mul_kernel", "row_fwd_kernel", "row_inv_kernel", "small_kernel",
               "permute_kernel", "crt_reduce_kernel", "crt_merge_kernel"):
         if k in name:

@@ -38,8 +38,10 @@ UNITS_PER_LAUNCH = 1024 / 22.0          # bench.py's default batch in 22 launche
 
 # (listing, substring of the mangled kernel name, SQ key in the profile summary, waves per product and pass)
 KERNELS = {
-    "col_fwd": ("kernels_col.hip", "col_kernelINS_6Mont32ELb1ELi6ELb0ELb1ELb0E", "col_kernel_fwd", 2 * 4096 / 64),
-    "row_mul": ("kernels_row.hip", "row_mul_kernelINS_6Mont32ELb1E", "row_mul_kernel", 64 * 256 / 64),
+    # round 3: the first forward pass is the software-pipelined walking kernel (its listing holds the walk's loop body
+    # once plus the prologue; the dynamic count comes from the counters), the row kernel has a WIDE variant for p < 2^29
+    "col_fwd": ("kernels_col.hip", "col_walk_prefetch_kernelINS_6Mont32ELb1ELi6ELb0E", "col_kernel_fwd", 2 * 4096 / 64),
+    "row_mul": ("kernels_row.hip", "row_mul_kernelINS_6Mont32ELb1ELb0E", "row_mul_kernel", 64 * 256 / 64),
     "col_inv": ("kernels_col16.hip", "col16_kernelINS_6Mont32ELb1ELi2ELb1ELb0E", "col16_kernel_inv", 4096 * 4 / 64),
 }
 
