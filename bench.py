@@ -526,6 +526,16 @@ def main(argv=None):
             group.close()
             return 1
         gpu_row0 = dab[0, :2 * n - 1].cpu().numpy().view(np.uint32).copy()
+        if world > 1 and rank == 0:
+            # one oracle row with N > 1 as well (with one rank the cpu_baseline leg below does it): checker only
+            import orc
+            want, _ = orc.poly_multiply_omp(ha[0].astype(np.uint64), hb[0].astype(np.uint64), p, threads=usable_cores()[0])
+            if not np.array_equal(np.asarray(want).astype(np.uint64), gpu_row0.astype(np.uint64)):
+                print("bench: rank 0: GPU result differs from the oracle", file=sys.stderr)
+                bad = 1.0
+        if group.max_over_ranks(bad) > 0:
+            group.close()
+            return 1
 
     # which kernel dominates (all kernels bracketed with events over two untimed steps); the timed region
     # then pays only for the events of the kernel it reports

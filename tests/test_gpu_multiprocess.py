@@ -88,21 +88,22 @@ def test_launcher_rank_layout(tmp_path, nttdata, world, backend):
     assert r.returncode == 1 and "多项式乘法结果错误" in r.stdout
 
 
-def test_bench_gpus_flag_on_one_gpu():
-    """bench.py called the way the driver calls it for N > 1 (no torchrun wrapper): it starts its two ranks itself;
-    over gloo both share this box's GPU.  One JSON line from rank 0 with n_gpus == 2; every rank has checked rows of
-    its own output before timing."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_gpus_flag_on_one_gpu(world):
+    """bench.py called the way the driver calls it for N > 1 (no torchrun wrapper): it starts its ranks itself;
+    over gloo they share this box's GPU.  One JSON line from rank 0 with n_gpus == world; every rank has checked rows of
+    its own output before timing, rank 0 one row against the oracle."""
     import json
     root = os.path.dirname(HERE)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--steps", "2",
                         "--warmup", "1", "--no-cpu-baseline", "--batch", "96", "--sustained-seconds", "0"],
                        env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["n_gpus"] == world and j["value"] > 0 and j["scaling"] == "weak"
     assert j["config"]["batch_per_gpu"] == 96 and j["roofline"]["kernel"] in ("row_mul", "col_fwd", "col_inv")
     # the other sharded workloads behind the headline loop (SURVEY 8e): prime-per-rank CRT with its exchange, RNS limbs
     # per rank, one 2^26-point transform split over the two ranks -- each timed, each checked on every rank
@@ -110,9 +111,11 @@ def test_bench_gpus_flag_on_one_gpu():
     assert also["checks"] == "ok", also
     for key in ("crt4_n2p17_ms", "crt4_GBps", "rns_32x256_n2p16_ms", "rns_products_per_s", "ntt2p26_fwd_inv_ms", "ntt2p26_GBps"):
         assert also[key] > 0, key
-    assert also["crt4_primes_per_rank"] == 2 and also["rns_limbs_per_rank"] == 16
-    assert also["crt4_sent_bytes_per_rank"] == ((2 * 131072 - 1 + 1) // 2) * (4 * 2 + 8)
-    assert also["ntt2p26_sent_bytes_per_rank"] == 4 * (1 << 24) * 4
+    # the rank-spanning CRT product runs at n = 2^17 here (4 primes over 2 or 4 ranks), against the oracle on rank 0
+    assert also["crt4_primes_per_rank"] == 4 // world and also["rns_limbs_per_rank"] == 32 // world
+    sl = -(-(2 * 131072 - 1) // world)
+    assert also["crt4_sent_bytes_per_rank"] == (world - 1) * sl * (4 * (4 // world) + 8)
+    assert also["ntt2p26_sent_bytes_per_rank"] == 4 * (world - 1) * ((1 << 26) // world // world) * 4
     assert j["roofline"]["binding"] == "valu-int" and 0 < j["roofline"]["valu_frac_of_coupled_peak"] < 1.2
 
 
