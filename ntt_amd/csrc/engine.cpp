@@ -23,6 +23,7 @@
 // (hipGetSymbolAddress in ntt_ctx_create, that device current) and kept in ntt_ctx::scratch; kernels,
 // like every other use of the memory, get that pointer, never the name.
 static constexpr size_t kScratchBytes = (size_t)64 << 20;
+static constexpr size_t kZeroCopyBytes = (size_t)1 << 20;     // per operand: pinned host arrays up to this size are used in place
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 // Every context on a GPU shares that GPU's copy of the array.  Calls are ordered per DEVICE, not per context: one
 // event per device marks the end of the last noalloc call there (created in ntt_ctx_create, so the call itself still
@@ -136,6 +137,17 @@ bool is_device_ptr(const void *p)
     hsa_device_type_t dt = HSA_DEVICE_TYPE_CPU;
     if (hsa_agent_get_info(info.agentOwner, HSA_AGENT_INFO_DEVICE, &dt) != HSA_STATUS_SUCCESS) return false;
     return dt == HSA_DEVICE_TYPE_GPU;
+}
+
+// Page-locked host memory this HIP runtime knows (hipHostMalloc / hipHostRegister): device-accessible at the same address
+bool is_pinned_host_ptr(const void *p)
+{
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeHost && at.devicePointer != nullptr;
 }
 
 // ---- table construction -------------------------------------------------------------------------
@@ -1088,10 +1100,19 @@ static int multiply_entry(ntt_plan *pl, const uint32_t *a, const uint32_t *b, ui
     ntt_ctx *cx = pl->ctx;
     std::lock_guard<std::mutex> lk(cx->mu);
     HIP_TRY(hipSetDevice(cx->device));
-    const bool da = is_device_ptr(a), db = is_device_ptr(b), dab = is_device_ptr(ab);
+    const size_t in_bytes = (size_t)batch * n * 4, out_elems = ((size_t)batch - 1) * ab_stride + out_len;
+    // Page-locked host arrays of a SMALL call (ntt_host_alloc / hipHostMalloc: mapped into the device's address space)
+    // are used in place: the first pass reads the operands and the last pass writes the result over PCIe, which costs
+    // less than three staging copies with a launch latency each when there is one product to move (93 -> 6x us per
+    // n = 2^17 product, profiles/latency_r03.txt).  Larger calls stage as before (DMA beats loads over the link).
+    const bool zero_copy = in_bytes <= kZeroCopyBytes;
+    bool da = is_device_ptr(a) || (zero_copy && is_pinned_host_ptr(a)), db = is_device_ptr(b) || (zero_copy && is_pinned_host_ptr(b));
+    bool dab = is_device_ptr(ab);
+    const bool host_out_in_place = !dab && zero_copy && is_pinned_host_ptr(ab);
+    dab = dab || host_out_in_place;
+    const bool host_in_place = host_out_in_place || !is_device_ptr(a) || !is_device_ptr(b);
     const uint32_t *pa = a, *pb = b;
     uint32_t *pab = ab;
-    const size_t in_bytes = (size_t)batch * n * 4, out_elems = ((size_t)batch - 1) * ab_stride + out_len;
     if (!da) {
         int rc = cx->stage_a.ensure(in_bytes);
         if (rc) return rc;
@@ -1118,8 +1139,8 @@ static int multiply_entry(ntt_plan *pl, const uint32_t *a, const uint32_t *b, ui
     if (!dab) {
         HIP_TRY(hipMemcpyAsync(ab, pab, out_elems * 4, hipMemcpyDeviceToHost, cx->stream));
         if (int src_ = sync_stream(cx)) return src_;
-    } else if (!da || !db) {
-        if (int src_ = sync_stream(cx)) return src_;   // host inputs may be reused by the caller
+    } else if (!da || !db || host_in_place) {
+        if (int src_ = sync_stream(cx)) return src_;   // host arrays: the call returns when they may be reused / are complete
     }
     return NTT_OK;
 }

@@ -51,6 +51,7 @@ const char *last_error_cstr();
 // NTT_OK, or NTT_ERR_INTERNAL (and the message) if a dispatcher skipped a launch since the last call; clears the mark
 int take_launch_error();
 bool is_device_ptr(const void *p);
+bool is_pinned_host_ptr(const void *p);    // page-locked host memory of this HIP runtime (device-accessible)
 int sync_stream(ntt_ctx *cx);              // engine.cpp: hipStreamSynchronize on the context's stream
 bool is_prime64(uint64_t n);              // direct64.cpp: deterministic Miller-Rabin
 

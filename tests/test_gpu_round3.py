@@ -278,3 +278,36 @@ def test_wide_range_kernels_for_primes_below_2pow29(nt, monkeypatch, n, batch):
                 got = outs[0].cpu().numpy().view(np.uint32)
                 for r in sorted({0, batch - 1}):
                     assert np.array_equal(got[r], orc.poly_multiply(a[r], b[r], p, kind="barrett")), (p, kind, r)
+
+
+def test_pinned_host_arrays_are_used_in_place(nt, ctx):
+    """Small calls on page-locked host arrays (ntt_host_alloc) run zero-copy: the first pass reads the operands and the last
+    pass writes the product over PCIe (engine.cpp, kZeroCopyBytes); larger calls and pageable arrays are staged.  Same
+    results every way, the oracle's; entries beyond 2n - 1 of a pinned output row stay untouched."""
+    p = 998244353
+    rng = np.random.default_rng(91)
+    for n, batch in ((131072, 1), (131072, 2), (1000, 3), (4096, 1), (2048, 2), (131072, 5)):
+        a, b = nt.host_array((batch, n)), nt.host_array((batch, n))
+        a[:] = rng.integers(0, p, size=(batch, n), dtype=np.int64).astype(np.uint32)
+        b[:] = rng.integers(0, p, size=(batch, n), dtype=np.int64).astype(np.uint32)
+        a[0, :] = p - 1
+        stride = 2 * n + 2
+        out = nt.host_array((batch, stride))
+        out[:] = 0xDEADBEEF
+        plan = ctx.plan(p, n, batch)
+        plan.multiply(a, b, out=out, batch=batch, out_stride=stride)              # pinned in, pinned out
+        paged = plan.multiply(np.array(a), np.array(b))                           # pageable copies of the same operands
+        mixed = plan.multiply(a, np.array(b))                                     # one of each
+        plan.close()
+        assert np.array_equal(out[:, :2 * n - 1], paged) and np.array_equal(mixed, paged), (n, batch)
+        assert bool((out[:, 2 * n - 1:] == 0xDEADBEEF).all())
+        for r in (0, batch - 1):
+            assert np.array_equal(paged[r], orc.poly_multiply(a[r], b[r], p)), (n, r)
+    # the reference's entry point on pinned int arrays
+    n = 131072
+    ia, ib = nt.host_array(n, np.int32), nt.host_array(n, np.int32)
+    ia[:] = rng.integers(0, p, size=n)
+    ib[:] = rng.integers(0, p, size=n)
+    iab = nt.host_array(2 * n - 1, np.int32)
+    nt._lib.poly_multiply(ia.ctypes.data, ib.ctypes.data, iab.ctypes.data, n, p)
+    assert np.array_equal(iab.view(np.uint32), orc.poly_multiply(ia.view(np.uint32), ib.view(np.uint32), p))
