@@ -177,12 +177,18 @@ class Context:
         _check(_lib.ntt_ctx_device(self._h, int(index), C.byref(h), C.byref(dev)))
         view = Context.__new__(Context)
         view._h, view.device, view.devices, view._plans, view._borrowed = h, dev.value, [dev.value], weakref.WeakSet(), self
+        self._views = getattr(self, "_views", [])
+        self._views.append(weakref.ref(view))           # its plans are closed with this context (they point into it)
         return view
 
     def close(self):
         """Destroys the context after closing every plan made from it that is still open (a plan handle
         holds a pointer to its context: destroying it later would be a use-after-free in native code)."""
         if self._h:
+            for ref in getattr(self, "_views", []):           # slot views handed out by slot(): their plans first
+                view = ref()
+                if view is not None:
+                    view.close()
             for pl in list(self._plans):
                 pl.close()
             if getattr(self, "_borrowed", None) is None:      # a slot view does not own its handle

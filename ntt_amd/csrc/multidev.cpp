@@ -307,10 +307,17 @@ int group_transform(ntt_plan *pl, uint32_t *data, int batch, bool inverse)
 }
 
 // ---- large-modulus product, prime per slot + one exchange ----------------------------------------------------------------
+static int group_crt_workspace_build(ntt_ctx *g, int n);
 static int group_crt_workspace(ntt_ctx *g, int n)
 {
-    const int nd = (int)g->sub.size();
     if (g->gcrt && g->gcrt->n == n) return NTT_OK;
+    const int rc = group_crt_workspace_build(g, n);
+    if (rc) group_crt_release(g);                           // never leave a half-built workspace behind for the next call
+    return rc;
+}
+static int group_crt_workspace_build(ntt_ctx *g, int n)
+{
+    const int nd = (int)g->sub.size();
     group_crt_release(g);
     std::unique_ptr<GroupCrt> w(new GroupCrt());
     w->n = n;
