@@ -417,6 +417,10 @@ def parse_args(argv=None):
     ap.add_argument("--sustained-seconds", type=float, default=2.5,
                     help="length of the untimed-by-the-driver loop behind `roofline.sustained` (0 = skip)")
     ap.add_argument("--no-one-lane", action="store_true", help="skip the one-lane per-kernel table")
+    ap.add_argument("--timing-stride", type=int, default=4,
+                    help="bracket every N-th launch of the dominant kernel with events in the timed region (1: all)")
+    ap.add_argument("--settle-seconds", type=float, default=1.0,
+                    help="untimed steps of the same work for this long in front of the timed region (power / clock steady state)")
     ap.add_argument("--no-also", action="store_true", help="skip the `also` block (CRT, RNS and 2^26 workloads behind the headline loop)")
     ap.add_argument("--also-timeout", type=float, default=90.0, help="watchdog of the `also` block, seconds")
     ap.add_argument("--with-ref", action="store_true",
@@ -548,6 +552,20 @@ def main(argv=None):
         warm_ktimes = {k: v for k, v in ctx.kernel_times().items() if v[1] > 0}
         dominant = max(warm_ktimes.items(), key=lambda kv: kv[1][0])[0]
         ctx.kernel_timing_select(dominant)
+        ctx.kernel_timing_stride(args.timing_stride)   # a sample of the timed region's launches (every 4th of 22 per step)
+    # settle: the board's power controller takes ~0.5 s of load to reach its steady clock (the loop
+    # over >= 2 s behind the timed region used to read 4-6 % above a timed region that started cold).  Untimed steps of
+    # the same work until --settle-seconds have passed, so that the K timed steps below see the steady state
+    settle_steps = 0
+    if args.settle_seconds > 0:
+        ctx.enable_kernel_timing(False)
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < args.settle_seconds:
+            for _ in range(10):
+                step()
+            sync()
+            settle_steps += 10
+        settle_steps = int(group.max_over_ranks(settle_steps))
     ctx.enable_kernel_timing(not args.no_kernel_timing)
     barrier()
     sync()
@@ -635,7 +653,10 @@ def main(argv=None):
         # dominant kernel = largest share of device time in the timed region
         name, (tot_ms, launches) = max(((k, v) for k, v in ktimes.items() if v[1] > 0),
                                        key=lambda kv: kv[1][0])
-        units_per_launch = B * args.steps / launches
+        # `launches` = the launches that carried events (every --timing-stride-th); the launches per step come from the
+        # two untimed steps in which every launch was bracketed
+        launches_per_step = warm_ktimes[name][1] / 2 if name in warm_ktimes else launches / args.steps
+        units_per_launch = B / launches_per_step
         avg_ms = tot_ms / launches
         achieved = alg_bytes * units_per_launch / (avg_ms * 1e-3) / 1e9
         stamp = kernel_source_stamp()
@@ -678,6 +699,7 @@ def main(argv=None):
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_steps_untimed": settle_steps,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
@@ -690,7 +712,7 @@ def main(argv=None):
                        "batch_per_gpu": B, "n": n, "p": p, "sharding": f"batch x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": name, "avg_launch_ms": avg_ms, "launches": launches,
+                         "kernel": name, "avg_launch_ms": avg_ms, "launches": launches, "launches_timed_every": args.timing_stride,
                          "units_per_launch": units_per_launch, "algorithmic_bytes_per_unit": alg_bytes,
                          "traffic_detail": traffic_info,
                          "pipeline_achieved": value / world * alg_bytes / 1e9,

@@ -274,6 +274,10 @@ int ntt_dist_plan_transport(const ntt_dist_plan *plan, int *transport, int *chun
  * that a timed region pays for the events of the kernel it reports only. */
 int ntt_ctx_enable_kernel_timing(ntt_ctx *ctx, int enable);
 int ntt_ctx_kernel_timing_select(ntt_ctx *ctx, int index);
+/* Bracket only every `every`-th launch of the selected kernel(s) (1: every launch): a sample of the launches of a timed
+ * region instead of all of them -- the events of a launch cost about as much as 1.5 % of the row kernel it brackets.
+ * ntt_ctx_kernel_time then reports the sampled launches (their count and their total). */
+int ntt_ctx_kernel_timing_stride(ntt_ctx *ctx, int every);
 int ntt_ctx_kernel_time(ntt_ctx *ctx, int index, const char **name, double *total_ms, long *launches);
 
 /* Thread-local message of the last failure in this thread ("" if none). */

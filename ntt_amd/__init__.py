@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = (
     "ntt_crt_residue_multiply", "ntt_crt_merge", "ntt_dist_plan_create", "ntt_dist_plan_destroy",
     "ntt_dist_colpass", "ntt_dist_local", "ntt_dist_local_length",
     "ntt_ctx_device_count", "ntt_ctx_device", "ntt_partition", "ntt_dist_forward", "ntt_dist_inverse", "ntt_dist_plan_transport",
-    "ntt_ctx_enable_kernel_timing", "ntt_ctx_kernel_timing_select", "ntt_ctx_kernel_time", "ntt_last_error", "ntt_read_case",
+    "ntt_ctx_enable_kernel_timing", "ntt_ctx_kernel_timing_select", "ntt_ctx_kernel_timing_stride", "ntt_ctx_kernel_time", "ntt_last_error", "ntt_read_case",
     "ntt_check_case", "ntt_write_case", "ntt_poly_multiply_stream", "ntt_host_alloc", "ntt_host_free",
     "ntt_pack_case", "ntt_read_case_bin", "ntt_check_case_bin", "ntt_write_case_bin",
 )
@@ -104,6 +104,7 @@ def _load():
     lib.ntt_dist_plan_transport.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.ntt_ctx_enable_kernel_timing.argtypes = [vp, i32]
     lib.ntt_ctx_kernel_timing_select.argtypes = [vp, i32]
+    lib.ntt_ctx_kernel_timing_stride.argtypes = [vp, i32]
     lib.ntt_ctx_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                         C.POINTER(C.c_long)]
     lib.ntt_last_error.restype = C.c_char_p
@@ -285,6 +286,10 @@ class Context:
                     break
                 i += 1
         _check(_lib.ntt_ctx_kernel_timing_select(self._h, index))
+
+    def kernel_timing_stride(self, every=1):
+        """Bracket only every `every`-th launch of the selected kernel(s)."""
+        _check(_lib.ntt_ctx_kernel_timing_stride(self._h, int(every)))
 
     def kernel_times(self):
         """{kernel name: (total ms, launches)} accumulated since timing was (re-)enabled."""

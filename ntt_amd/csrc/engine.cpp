@@ -382,9 +382,16 @@ static void row_pass(ntt_plan *pl, int which, const uint32_t *a0, const uint32_t
     ntt_ctx *cx = pl->ctx;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     static const bool ext_events = [] { const char *e = std::getenv("NTT_AMD_EXT_EVENTS"); return !(e && e[0] == '0'); }();
-    if (which == 0 && ext_events && cx->begin_ext(K_ROW_MUL, &e0, &e1)) {
-        launch_row_mul_timed(pl->kind, pl->lazy_mode(), &a, pl->mp, rows, cx->cur, e0, e1);
-        return;
+    if (which == 0 && ext_events) {
+        const int st = cx->begin_ext(K_ROW_MUL, &e0, &e1);     // 1: this launch carries events; -1: skipped by the sampling stride
+        if (st == 1) {
+            launch_row_mul_timed(pl->kind, pl->lazy_mode(), &a, pl->mp, rows, cx->cur, e0, e1);
+            return;
+        }
+        if (st == -1) {
+            launch_row_mul(pl->kind, pl->lazy_mode(), &a, pl->mp, rows, cx->cur);
+            return;
+        }
     }
     cx->begin(which == 0 ? K_ROW_MUL : which == 1 ? K_ROW_FWD : K_ROW_INV);
     if (which == 0) launch_row_mul(pl->kind, pl->lazy_mode(), &a, pl->mp, rows, cx->cur);
@@ -709,6 +716,7 @@ hipEvent_t ntt_ctx::grab_event()
 void ntt_ctx::begin(int id)
 {
     stamp_open = timing && (timing_only < 0 || timing_only == id);
+    if (stamp_open && timing_stride > 1 && (timing_tick++ % timing_stride) != 0) stamp_open = false;
     if (!stamp_open) return;
     Stamp s{id, grab_event(), grab_event()};
     if (!s.e0 || !s.e1 || hipEventRecord(s.e0, cur ? cur : stream) != hipSuccess) {   // timing is diagnostic only
@@ -719,20 +727,21 @@ void ntt_ctx::begin(int id)
     }
     stamps.push_back(s);
 }
-bool ntt_ctx::begin_ext(int id, hipEvent_t *e0, hipEvent_t *e1)
+int ntt_ctx::begin_ext(int id, hipEvent_t *e0, hipEvent_t *e1)
 {
     stamp_open = false;
-    if (!(timing && (timing_only < 0 || timing_only == id))) return false;
+    if (!(timing && (timing_only < 0 || timing_only == id))) return 0;
+    if (timing_stride > 1 && (timing_tick++ % timing_stride) != 0) return -1;
     Stamp s{id, grab_event(), grab_event()};
     if (!s.e0 || !s.e1) {
         if (s.e0) event_pool.push_back(s.e0);
         if (s.e1) event_pool.push_back(s.e1);
-        return false;
+        return -1;
     }
     stamps.push_back(s);
     *e0 = s.e0;
     *e1 = s.e1;
-    return true;
+    return 1;
 }
 void ntt_ctx::end()
 {
@@ -861,6 +870,18 @@ try {
     std::lock_guard<std::mutex> lk(ctx->mu);
     int rc = ctx->fold();
     ctx->timing_only = index;
+    return rc;
+}
+NTT_CATCH_STATUS
+
+int ntt_ctx_kernel_timing_stride(ntt_ctx *ctx, int every)
+try {
+    if (!ctx || every < 1) return fail(NTT_ERR_INVALID, "ntt_ctx_kernel_timing_stride: every must be >= 1");
+    if (ctx->is_group()) return fail(NTT_ERR_UNSUPPORTED, "kernel timing is per slot: use ntt_ctx_device(ctx, slot)");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ctx->fold();
+    ctx->timing_stride = every;
+    ctx->timing_tick = 0;
     return rc;
 }
 NTT_CATCH_STATUS

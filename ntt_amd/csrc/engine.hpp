@@ -127,6 +127,7 @@ struct ntt_ctx {
     // per-kernel timing (bench.py roofline block)
     bool timing = false;
     int timing_only = -1;                             // >= 0: bracket only this kernel id
+    int timing_stride = 1, timing_tick = 0;           // bracket every timing_stride-th launch of the selected kernel(s)
     bool stamp_open = false;                          // begin() recorded a start event
     struct Stamp { int id; hipEvent_t e0, e1; };
     std::vector<Stamp> stamps;
@@ -135,8 +136,9 @@ struct ntt_ctx {
     long acc_n[ntt::K_COUNT] = {0};
     void begin(int id);
     void end();
-    // for launches that carry their own start / stop events: true (and the pair) when this launch is to be timed
-    bool begin_ext(int id, hipEvent_t *e0, hipEvent_t *e1);
+    // for launches that carry their own start / stop events: 1 (and the pair) when this launch is to be timed, -1 when
+    // timing is on for this kernel but this launch is not in the sample (timing_stride), 0 when timing does not apply
+    int begin_ext(int id, hipEvent_t *e0, hipEvent_t *e1);
     int fold();                                       // sync + accumulate + recycle events
     hipEvent_t grab_event();
 
