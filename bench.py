@@ -380,6 +380,32 @@ def also_block(args, group, rank, world, local_rank):
     else:
         out["ntt2p26_skipped"] = "needs a power-of-two number of ranks"
     ctx.close()
+    # (d) the same exchanges INSIDE the C++ library: one process over all the job's GPUs (ntt_ctx_create with ndev > 1,
+    # multidev.cpp) -- peer copies for the CRT slices, peer loads / stores in the column kernel for the split transform.
+    # Rank 0 runs it as a CHILD process while the other ranks wait: those paths have only ever run with repeated device
+    # ids on one GPU, and a fault there must not take this line along (tools/mdev_bench.py)
+    if world > 1:
+        torch.cuda.synchronize()
+        group.barrier()
+        if rank == 0:
+            ndev_seen = max(1, torch.cuda.device_count())
+            devs = [r % ndev_seen for r in range(world)] if on_device else [local_rank % ndev_seen] * world
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mdev_bench.py"), "--devices",
+                                    ",".join(str(d) for d in devs)], capture_output=True, text=True,
+                                   timeout=max(20.0, args.also_timeout / 2))
+                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if lines:
+                    md = json.loads(lines[-1])
+                    out.update({k: v for k, v in md.items() if k.startswith("mdev_")})
+                    out["mdev_devices"] = ",".join(str(d) for d in md["devices"])
+                    if md.get("mdev_checks") != "ok":
+                        failed.append("in-library multi-device path")
+                else:
+                    out["mdev_error"] = f"exit {r.returncode}: {r.stderr[-200:]}"
+            except subprocess.TimeoutExpired:
+                out["mdev_error"] = "timeout"
+        group.barrier()
     nfailed = group.sum_over_ranks(float(len(failed)))
     out["checks"] = "ok" if nfailed == 0 else "FAILED on some rank: " + ", ".join(failed)
     return out
@@ -422,7 +448,7 @@ def parse_args(argv=None):
     ap.add_argument("--settle-seconds", type=float, default=1.0,
                     help="untimed steps of the same work for this long in front of the timed region (power / clock steady state)")
     ap.add_argument("--no-also", action="store_true", help="skip the `also` block (CRT, RNS and 2^26 workloads behind the headline loop)")
-    ap.add_argument("--also-timeout", type=float, default=90.0, help="watchdog of the `also` block, seconds")
+    ap.add_argument("--also-timeout", type=float, default=150.0, help="watchdog of the `also` block, seconds")
     ap.add_argument("--with-ref", action="store_true",
                     help="cpu_baseline also times oracle/_ref (the reference's main-baseline.cc compiled in the build container); "
                          "off by default: the default run executes nothing built from /root/reference")

@@ -117,6 +117,10 @@ def test_bench_gpus_flag_on_one_gpu(world):
     assert also["crt4_sent_bytes_per_rank"] == (world - 1) * sl * (4 * (4 // world) + 8)
     assert also["ntt2p26_sent_bytes_per_rank"] == 4 * (world - 1) * ((1 << 26) // world // world) * 4
     assert j["roofline"]["binding"] == "valu-int" and 0 < j["roofline"]["valu_frac_of_coupled_peak"] < 1.2
+    # ... and the in-library multi-device path (one process over all slots), run by rank 0 as a child process
+    assert also.get("mdev_checks") == "ok", also
+    assert also["mdev_devices"] == ",".join(["0"] * world) and also["mdev_crt4_n2p17_ms"] > 0
+    assert also["mdev_ntt2p26_p2p_fwd_inv_ms"] > 0 and also["mdev_ntt2p26_copy_fwd_inv_ms"] > 0
 
 
 def test_bench_also_block_one_rank():
