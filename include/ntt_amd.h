@@ -265,6 +265,14 @@ int ntt_dist_local_length(const ntt_dist_plan *plan);
 int ntt_dist_forward(ntt_dist_plan *plan, const uint32_t *const *in, uint32_t *const *out);
 int ntt_dist_inverse(ntt_dist_plan *plan, const uint32_t *const *in, uint32_t *const *out);
 int ntt_dist_plan_transport(const ntt_dist_plan *plan, int *transport, int *chunks);
+/* The product of two polynomials too long for one GPU to want, on a plan of a multi-device context: a and b have
+ * n = L / 2 coefficients, block r (S = L / world of them) of each on the device of slot r for r < world / 2 (a[r], b[r]
+ * for r >= world / 2 are not read: that half of the transform is the zero padding); ab[r], r < world, receives block r of
+ * the L - 1 product coefficients (canonical; the last element of the last block is 0).  The harness multiply body
+ * main-montgomery.cc:326-351 -- pad, NTT, NTT, pointwise product :341-344, inverse NTT -- with each transform split as
+ * above, the exchanges inside the library, and no reordering pass anywhere: the spectra stay in the engine's own order
+ * between the forward and the inverse transform.  a, b are not modified; queued like ntt_dist_forward. */
+int ntt_dist_multiply(ntt_dist_plan *plan, const uint32_t *const *a, const uint32_t *const *b, uint32_t *const *ab);
 
 /* Per-kernel timing (HIP events on the context's stream) for bench.py's roofline block.
  * With timing enabled every kernel launch is bracketed by events; ntt_ctx_kernel_time returns

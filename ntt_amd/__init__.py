@@ -43,7 +43,7 @@ EXPORTED_SYMBOLS = (
     "ntt_plan64_create", "ntt_plan64_destroy", "ntt_plan64_length", "ntt_poly_multiply64_batched",
     "ntt_crt_residue_multiply", "ntt_crt_merge", "ntt_dist_plan_create", "ntt_dist_plan_destroy",
     "ntt_dist_colpass", "ntt_dist_local", "ntt_dist_local_length",
-    "ntt_ctx_device_count", "ntt_ctx_device", "ntt_partition", "ntt_dist_forward", "ntt_dist_inverse", "ntt_dist_plan_transport",
+    "ntt_ctx_device_count", "ntt_ctx_device", "ntt_partition", "ntt_dist_forward", "ntt_dist_inverse", "ntt_dist_plan_transport", "ntt_dist_multiply",
     "ntt_ctx_enable_kernel_timing", "ntt_ctx_kernel_timing_select", "ntt_ctx_kernel_timing_stride", "ntt_ctx_kernel_time", "ntt_last_error", "ntt_read_case",
     "ntt_check_case", "ntt_write_case", "ntt_poly_multiply_stream", "ntt_host_alloc", "ntt_host_free",
     "ntt_pack_case", "ntt_read_case_bin", "ntt_check_case_bin", "ntt_write_case_bin",
@@ -102,6 +102,7 @@ def _load():
     lib.ntt_dist_forward.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.ntt_dist_inverse.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.ntt_dist_plan_transport.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    lib.ntt_dist_multiply.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.ntt_ctx_enable_kernel_timing.argtypes = [vp, i32]
     lib.ntt_ctx_kernel_timing_select.argtypes = [vp, i32]
     lib.ntt_ctx_kernel_timing_stride.argtypes = [vp, i32]
@@ -492,6 +493,17 @@ class DistPlan:
     def inverse(self, blocks_in, blocks_out):
         _check(_lib.ntt_dist_inverse(self._h, self._blocks(blocks_in), self._blocks(blocks_out)))
         return blocks_out
+
+    def multiply(self, a_blocks, b_blocks, ab_blocks):
+        """Multi-device plan: the product of two polynomials of L/2 coefficients held as world/2 blocks each (block r on
+        slot r) into world blocks of the L-1 product coefficients (``ntt_dist_multiply``; queued)."""
+        half = self.world // 2
+        if len(a_blocks) != half or len(b_blocks) != half:
+            raise ValueError(f"expected {half} operand blocks (the upper half of the transform is zero padding)")
+        pad = [None] * (self.world - half)
+        arr = lambda xs: (C.c_void_p * self.world)(*[_ptr(x, np.uint32, self.local_length).value if x is not None else None for x in xs])
+        _check(_lib.ntt_dist_multiply(self._h, arr(list(a_blocks) + pad), arr(list(b_blocks) + pad), self._blocks(ab_blocks)))
+        return ab_blocks
 
 
 class _PinnedOwner:

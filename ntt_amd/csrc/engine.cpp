@@ -650,8 +650,11 @@ static void permute_pass(ntt_plan *pl, const uint32_t *src, uint32_t *dst, bool 
 
 // src, data: DEVICE pointers, [batch][L]; natural order in and out.  src == data transforms in place; otherwise src
 // is only read (the first pass of either direction takes it as its input) and the result lands in data.
+// scrambled: the spectrum stays in the engine's own (mixed-radix digit-reversed) order and range -- forward without the
+// final permutation, inverse without the initial one -- which is all a pointwise product between the two needs
+// (L > 4096 only; shorter transforms have no permutation pass and keep natural order either way).
 template <class MM>
-static int transform_device(ntt_plan *pl, const uint32_t *src, uint32_t *data, int batch, bool inverse)
+static int transform_device(ntt_plan *pl, const uint32_t *src, uint32_t *data, int batch, bool inverse, bool scrambled = false)
 {
     const uint32_t L = pl->L;
     pl->ctx->cur = pl->ctx->stream;
@@ -669,11 +672,18 @@ static int transform_device(ntt_plan *pl, const uint32_t *src, uint32_t *data, i
             for (int j = 0; j < m; ++j)
                 col_pass<MM>(pl, j, false, false, j == 0 ? s : d, nullptr, d, nullptr, L, L, L, L, pl->tw_fwd[j], false,
                              {}, false, cb, 1);
-            row_pass<MM>(pl, 1, d, nullptr, w0, cb * (L >> kRowLog));
-            permute_pass(pl, w0, d, true, cb);
+            if (scrambled) {
+                row_pass<MM>(pl, 1, d, nullptr, d, cb * (L >> kRowLog));     // in place: a row is read before it is written
+            } else {
+                row_pass<MM>(pl, 1, d, nullptr, w0, cb * (L >> kRowLog));
+                permute_pass(pl, w0, d, true, cb);
+            }
         } else {
-            permute_pass(pl, s, w0, false, cb);
-            row_pass<MM>(pl, 2, w0, nullptr, w0, cb * (L >> kRowLog));
+            if (scrambled) row_pass<MM>(pl, 2, s, nullptr, w0, cb * (L >> kRowLog));
+            else {
+                permute_pass(pl, s, w0, false, cb);
+                row_pass<MM>(pl, 2, w0, nullptr, w0, cb * (L >> kRowLog));
+            }
             for (int j = m - 1; j >= 0; --j)
                 col_pass<MM>(pl, j, true, false, w0, nullptr, j == 0 ? d : w0, nullptr, L, L, L, L,
                              j == m - 1 ? pl->tw_inv_plain : pl->tw_inv[j], j == m - 1, pl->scale_plain,
@@ -685,13 +695,13 @@ static int transform_device(ntt_plan *pl, const uint32_t *src, uint32_t *data, i
 
 // One transform of the plan's length from src to dst (DEVICE pointers on the plan's GPU, src == dst allowed), queued
 // on the context's stream: the local S-point transforms of the in-library distributed transform (multidev.cpp).
-int transform_device_any(ntt_plan *pl, const uint32_t *src, uint32_t *dst, bool inverse)
+int transform_device_any(ntt_plan *pl, const uint32_t *src, uint32_t *dst, bool inverse, bool scrambled)
 {
     ntt_ctx *cx = pl->ctx;
     std::lock_guard<std::mutex> lk(cx->mu);
     HIP_TRY(hipSetDevice(cx->device));
-    const int rc = pl->kind == NTT_MODMUL_MONTGOMERY ? transform_device<Mont32>(pl, src, dst, 1, inverse)
-                                                     : transform_device<Barrett32>(pl, src, dst, 1, inverse);
+    const int rc = pl->kind == NTT_MODMUL_MONTGOMERY ? transform_device<Mont32>(pl, src, dst, 1, inverse, scrambled)
+                                                     : transform_device<Barrett32>(pl, src, dst, 1, inverse, scrambled);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return take_launch_error();

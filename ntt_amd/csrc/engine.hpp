@@ -71,7 +71,7 @@ struct WorkArea {
 int multiply_device_any(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
                         size_t ab_stride, int batch, const WorkArea *area = nullptr);
 // one transform of the plan's length, src -> dst (device pointers on the plan's GPU; src == dst allowed), on the context's stream
-int transform_device_any(ntt_plan *pl, const uint32_t *src, uint32_t *dst, bool inverse);
+int transform_device_any(ntt_plan *pl, const uint32_t *src, uint32_t *dst, bool inverse, bool scrambled = false);
 
 // ---- multi-device ("group") contexts: ntt_ctx_create with ndev > 1 (multidev.cpp) ----------------------------------
 // (start, count) of the contiguous block of `total` units owned by slot `rank` of `world`: ceil(total / world) units per
@@ -215,6 +215,7 @@ struct ntt_dist_plan {
     std::vector<ntt_dist_plan *> part;
     struct GroupSlot {
         ntt::DeviceBuffer held, sendbuf, rowbuf;          // [world][S/world] staging (copy transports), local inverse output
+        ntt::DeviceBuffer spec_a, spec_b, zeros;          // ntt_dist_multiply: the two spectra of this slot, a block of zero padding
         hipStream_t copy_in = nullptr, copy_out = nullptr;
         hipEvent_t start = nullptr, ready = nullptr, done = nullptr, fin = nullptr, out_done = nullptr;
         std::vector<hipEvent_t> ev_in, ev_k;              // per column chunk

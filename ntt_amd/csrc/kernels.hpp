@@ -220,6 +220,9 @@ struct DistColArgs {
     Roots64<MM> roots;                   // forward or inverse w_64 powers (the G-th root is a stride of them)
 };
 bool launch_dist_col(int kind, bool lazy, int logG, bool inverse, const void *args, const ModParams &mp, hipStream_t s);
+// a[i] = a[i] * b[i] mod p for two spectra of one transform (scrambled order; values in the engine's lazy range):
+// the pointwise product of main-montgomery.cc:341-344 between the halves of a split product
+void launch_dist_pointwise(int kind, bool lazy, uint32_t *a, const uint32_t *b, size_t count, const ModParams &mp, hipStream_t s);
 
 // ---- direct 64-bit path (kernels_u64.hip): one NTT-friendly prime p < 2^62, Montgomery R = 2^64 ---------
 struct ModParams64 {

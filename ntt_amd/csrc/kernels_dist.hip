@@ -62,6 +62,39 @@ static bool launch_dist_l(int logG, bool inverse, const DistColArgs<MM> &a, cons
 #undef NTT_DIST_CASE
 }
 
+// Pointwise product of two spectra (main-montgomery.cc:341-344).  Montgomery: REDC(a b) carries R^-1; one more
+// multiplication by R (table form R^2 mod p) removes it, so that the inverse transform's plain L^-1 scale applies.
+template <class MM, bool LAZY>
+__global__ void __launch_bounds__(256) dist_pointwise_kernel(uint32_t *__restrict__ a, const uint32_t *__restrict__ b, size_t count,
+                                                             const ModParams m)
+{
+    using O = Ops<MM, LAZY>;
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= count) return;                                             // count is a multiple of 4 (a power of two >= 256)
+    const uint4 va = *reinterpret_cast<const uint4 *>(a + i), vb = *reinterpret_cast<const uint4 *>(b + i);
+    uint32_t x[4] = {va.x, va.y, va.z, va.w};
+    const uint32_t y[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t t = O::mul(x[k], y[k], m);
+        if constexpr (MM::kMontgomery) t = O::mul_tw(t, typename MM::tw_t(m.r2), m);
+        x[k] = t;
+    }
+    *reinterpret_cast<uint4 *>(a + i) = make_uint4(x[0], x[1], x[2], x[3]);
+}
+
+void launch_dist_pointwise(int kind, bool lazy, uint32_t *a, const uint32_t *b, size_t count, const ModParams &mp, hipStream_t s)
+{
+    const dim3 grid((unsigned)((count / 4 + 255) / 256)), block(256);
+    if (kind == 0) {
+        if (lazy) hipLaunchKernelGGL((dist_pointwise_kernel<Mont32, true>), grid, block, 0, s, a, b, count, mp);
+        else hipLaunchKernelGGL((dist_pointwise_kernel<Mont32, false>), grid, block, 0, s, a, b, count, mp);
+    } else {
+        if (lazy) hipLaunchKernelGGL((dist_pointwise_kernel<Barrett32, true>), grid, block, 0, s, a, b, count, mp);
+        else hipLaunchKernelGGL((dist_pointwise_kernel<Barrett32, false>), grid, block, 0, s, a, b, count, mp);
+    }
+}
+
 bool launch_dist_col(int kind, bool lazy, int logG, bool inverse, const void *args, const ModParams &mp, hipStream_t s)
 {
     if (kind == 0) {

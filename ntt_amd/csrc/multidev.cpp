@@ -448,6 +448,7 @@ void group_dist_plan_release(ntt_dist_plan *dp)
         for (hipEvent_t e : gs.ev_in) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : gs.ev_k) if (e) (void)hipEventDestroy(e);
         gs.held.release(); gs.sendbuf.release(); gs.rowbuf.release();
+        gs.spec_a.release(); gs.spec_b.release(); gs.zeros.release();
     }
     dp->gslot.clear();
     if (!dp->comms.empty())
@@ -565,7 +566,9 @@ static int launch_slot_colpass(ntt_dist_plan *dp, int h, bool inverse, const uin
 
 // Forward: in[r] = x[r * S .. (r + 1) * S) on slot r  ->  out[r][k2] = X[r + world * k2].
 // Inverse: the reverse, scaled by L^-1.  Everything is queued; ntt_ctx_synchronize(group) waits for it.
-static int group_dist_run(ntt_dist_plan *dp, const uint32_t *const *in, uint32_t *const *out, bool inverse)
+// scrambled: the local transforms leave / take the spectrum in the engine's own order (no permutation pass): the two
+// halves of ntt_dist_multiply.
+static int group_dist_run(ntt_dist_plan *dp, const uint32_t *const *in, uint32_t *const *out, bool inverse, bool scrambled = false)
 {
     ntt_ctx *g = dp->ctx;
     const int G = dp->world;
@@ -583,7 +586,7 @@ static int group_dist_run(ntt_dist_plan *dp, const uint32_t *const *in, uint32_t
     if (inverse) {
         for (int r = 0; r < G; ++r) {
             uint32_t *rb = static_cast<uint32_t *>(dp->gslot[(size_t)r].rowbuf.ptr);
-            if (int rc = transform_device_any(dp->part[(size_t)r]->local, in[r], rb, true)) return rc;
+            if (int rc = transform_device_any(dp->part[(size_t)r]->local, in[r], rb, true, scrambled)) return rc;
             HIP_TRY(hipEventRecord(dp->gslot[(size_t)r].ready, g->sub[(size_t)r]->stream));
             rows[(size_t)r] = rb;
         }
@@ -687,10 +690,54 @@ static int group_dist_run(ntt_dist_plan *dp, const uint32_t *const *in, uint32_t
         for (int h = 0; h < G; ++h)
             if (h != r) HIP_TRY(hipStreamWaitEvent(c->stream, dp->gslot[(size_t)h].done, 0));
         if (!inverse)
-            if (int rc = transform_device_any(dp->part[(size_t)r]->local, out[r], out[r], false)) return rc;
+            if (int rc = transform_device_any(dp->part[(size_t)r]->local, out[r], out[r], false, scrambled)) return rc;
         HIP_TRY(hipEventRecord(dp->gslot[(size_t)r].fin, c->stream));
     }
     return NTT_OK;
+}
+
+// ab = a * b for two polynomials of n = L / 2 coefficients whose blocks of S live on the slots (block r of a and b on
+// slot r < world / 2; the upper half of the transform is zero padding): the harness multiply body
+// (main-montgomery.cc:326-351) at a size one GPU need not hold -- forward split transform of a and of b (spectra stay in
+// the engine's order: no permutation pass), pointwise product on every slot, inverse split transform into ab.
+static int group_dist_multiply(ntt_dist_plan *dp, const uint32_t *const *a, const uint32_t *const *b, uint32_t *const *ab)
+{
+    ntt_ctx *g = dp->ctx;
+    const int G = dp->world;
+    const size_t bytes = (size_t)dp->S * sizeof(uint32_t);
+    std::vector<const uint32_t *> ina((size_t)G), inb((size_t)G), spa_c((size_t)G);
+    std::vector<uint32_t *> spa((size_t)G), spb((size_t)G);
+    for (int r = 0; r < G; ++r) {
+        auto &gs = dp->gslot[(size_t)r];
+        ntt_ctx *c = g->sub[(size_t)r];
+        HIP_TRY(hipSetDevice(c->device));
+        int rc = gs.spec_a.ensure(bytes);
+        if (!rc) rc = gs.spec_b.ensure(bytes);
+        if (rc) return rc;
+        if (r >= G / 2 && !gs.zeros.ptr) {                   // the zero padding of both operands, written once
+            if ((rc = gs.zeros.ensure(bytes))) return rc;
+            HIP_TRY(hipMemsetAsync(gs.zeros.ptr, 0, bytes, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));        // peers read it from their own streams: complete before anyone can
+        }
+        ina[(size_t)r] = r < G / 2 ? a[r] : static_cast<const uint32_t *>(gs.zeros.ptr);
+        inb[(size_t)r] = r < G / 2 ? b[r] : static_cast<const uint32_t *>(gs.zeros.ptr);
+        spa[(size_t)r] = static_cast<uint32_t *>(gs.spec_a.ptr);
+        spb[(size_t)r] = static_cast<uint32_t *>(gs.spec_b.ptr);
+        spa_c[(size_t)r] = spa[(size_t)r];
+    }
+    int rc = group_dist_run(dp, ina.data(), spa.data(), false, true);
+    if (!rc) rc = group_dist_run(dp, inb.data(), spb.data(), false, true);
+    if (rc) return rc;
+    for (int r = 0; r < G; ++r) {                            // behind the slot's own local transforms (stream order)
+        ntt_ctx *c = g->sub[(size_t)r];
+        ntt_plan *lp = dp->part[(size_t)r]->local;
+        HIP_TRY(hipSetDevice(c->device));
+        launch_dist_pointwise(lp->kind, lp->lazy, spa[(size_t)r], spb[(size_t)r], dp->S, lp->mp, c->stream);
+        // the next run starts behind `fin` of every slot: move the mark behind the pointwise product
+        HIP_TRY(hipEventRecord(dp->gslot[(size_t)r].fin, c->stream));
+    }
+    HIP_TRY(hipGetLastError());
+    return group_dist_run(dp, spa_c.data(), ab, true, true);
 }
 
 }  // namespace ntt
@@ -750,6 +797,27 @@ NTT_CATCH_STATUS
 int ntt_dist_inverse(ntt_dist_plan *plan, const uint32_t *const *in, uint32_t *const *out)
 try {
     return dist_run_entry(plan, in, out, true, "ntt_dist_inverse");
+}
+NTT_CATCH_STATUS
+
+int ntt_dist_multiply(ntt_dist_plan *dp, const uint32_t *const *a, const uint32_t *const *b, uint32_t *const *ab)
+try {
+    const char *who = "ntt_dist_multiply";
+    if (!dp || !a || !b || !ab) return fail(NTT_ERR_INVALID, std::string(who) + ": null argument");
+    if (dp->part.empty()) return fail(NTT_ERR_INVALID, std::string(who) + ": needs a plan made from a multi-device context");
+    ntt_ctx *g = dp->ctx;
+    for (int r = 0; r < dp->world; ++r) {
+        const int want = g->sub[(size_t)r]->device;
+        const void *ptrs[3] = {r < dp->world / 2 ? a[r] : ab[r], r < dp->world / 2 ? b[r] : ab[r], ab[r]};
+        for (const void *p : ptrs) {
+            if (!p) return fail(NTT_ERR_INVALID, std::string(who) + ": null block pointer");
+            const int d = pointer_device(p);
+            if (d == -1) return fail(NTT_ERR_INVALID, std::string(who) + ": blocks must be device arrays");
+            if (d >= 0 && d != want) return fail(NTT_ERR_INVALID, std::string(who) + ": block " + std::to_string(r) + " must live on the device of slot " + std::to_string(r));
+        }
+    }
+    std::lock_guard<std::mutex> lk(dp->gmu);
+    return group_dist_multiply(dp, a, b, ab);
 }
 NTT_CATCH_STATUS
 

@@ -308,3 +308,77 @@ def test_group_dist_rccl_transport_is_refused_on_repeated_devices(nt, monkeypatc
     assert dp.transport[0] == "p2p"
     dp.close()
     g.close()
+
+
+@pytest.mark.parametrize("lgL,ndev,transport,kind_name,p", [
+    (16, 2, "p2p", "MONTGOMERY", 998244353), (16, 4, "copy", "BARRETT", 998244353), (18, 4, "copyin", "MONTGOMERY", 469762049),
+    (20, 8, "p2p", "MONTGOMERY", 1224736769), (20, 16, "p2p", "BARRETT", 469762049), (14, 2, "p2p", "MONTGOMERY", 7340033),
+    (14, 4, "p2p", "MONTGOMERY", 7340033), (12, 2, "copy", "BARRETT", 104857601)])
+def test_group_dist_multiply(nt, monkeypatch, lgL, ndev, transport, kind_name, p):
+    """ntt_dist_multiply: the product of two polynomials of L / 2 coefficients held as blocks on the slots -- forward
+    split transform twice, pointwise product, inverse split transform, the spectra never reordered -- against the
+    oracle's poly_multiply (main-barrett.cc:249-282 body; a lazy, a wide-range and a strict prime, both kernel families,
+    a local length of 4096 and below included) and unchanged operands."""
+    import torch
+    monkeypatch.setenv("NTT_AMD_DIST_TRANSPORT", transport)
+    kind = getattr(nt, kind_name)
+    L, S, n = 1 << lgL, (1 << lgL) // ndev, (1 << lgL) // 2
+    rng = np.random.default_rng(lgL * 7 + ndev)
+    a = rng.integers(0, p, size=n, dtype=np.int64).astype(np.uint32)
+    b = rng.integers(0, p, size=n, dtype=np.int64).astype(np.uint32)
+    a[:100] = p - 1
+    b[:100] = p - 1
+    g = nt.Context(devices=[0] * ndev)
+    dp = nt.DistPlan(g, p, lgL, ndev, 0, kind)
+    half = ndev // 2
+    ab_ = [torch.from_numpy(a[r * S:(r + 1) * S].view(np.int32).copy()).cuda() for r in range(half)]
+    bb_ = [torch.from_numpy(b[r * S:(r + 1) * S].view(np.int32).copy()).cuda() for r in range(half)]
+    out = [torch.full((S,), -1, dtype=torch.int32, device="cuda") for _ in range(ndev)]
+    torch.cuda.synchronize()
+    for _ in range(2):                                       # twice on one plan: spectra buffers and events reused
+        dp.multiply(ab_, bb_, out)
+    g.synchronize()
+    got = torch.cat(out).cpu().numpy().view(np.uint32)
+    want = orc.poly_multiply(a, b, p, kind="barrett")
+    assert np.array_equal(got[:L - 1], want) and got[L - 1] == 0
+    for r in range(half):
+        assert np.array_equal(ab_[r].cpu().numpy().view(np.uint32), a[r * S:(r + 1) * S])
+    dp.close()
+    g.close()
+
+
+def test_group_dist_multiply_2pow26_over_8_slots(nt):
+    """The split product at L = 2^26 (two polynomials of 2^25 coefficients) over 8 slots against the single-context
+    product of the same operands (itself oracle-checked at this size by test_largest_product...) and the evaluation
+    identity A(x) B(x) = AB(x) at three points."""
+    import torch
+    from bench import _eval_point_t
+    p, lgL, ndev = 469762049, 26, 8
+    L, S, n = 1 << lgL, (1 << lgL) // ndev, (1 << lgL) // 2
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(2626)
+    a = torch.randint(0, p, (n,), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32)
+    b = torch.randint(0, p, (n,), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32)
+    g = nt.Context(devices=[0] * ndev)
+    dp = nt.DistPlan(g, p, lgL, ndev, 0)
+    ab_ = [a[r * S:(r + 1) * S].clone() for r in range(ndev // 2)]
+    bb_ = [b[r * S:(r + 1) * S].clone() for r in range(ndev // 2)]
+    out = [torch.full((S,), -1, dtype=torch.int32, device="cuda") for _ in range(ndev)]
+    torch.cuda.synchronize()
+    dp.multiply(ab_, bb_, out)
+    g.synchronize()
+    got = torch.cat(out)
+    dp.close()
+    g.close()
+    assert int(got[L - 1].item()) == 0 and int(got.max().item()) < p and int(got.min().item()) >= 0
+    for x in (1, p - 1, 0x2545F491 % p):
+        ea, eb, eab = _eval_point_t(torch, a, x, p), _eval_point_t(torch, b, x, p), _eval_point_t(torch, got, x, p)
+        assert ea * eb % p == eab, x
+    single = nt.Context(0)
+    plan = single.plan(p, n, 1)
+    want = torch.full((2 * n - 1,), -1, dtype=torch.int32, device="cuda")
+    plan.multiply(a.view(1, n), b.view(1, n), out=want.view(1, -1), batch=1)
+    single.synchronize()
+    assert torch.equal(got[:L - 1], want)
+    plan.close()
+    single.close()

@@ -7,7 +7,7 @@ library's own exchanges -- peer copies for the CRT slices, peer loads / stores i
 transform -- have only ever run with repeated device ids on one GPU, so a fault here must not take the headline line
 along.  Workloads: (2) the 4-prime CRT product at n = 2^17, prime per device + slice exchange
 (main-mpi.cc:657-660, 739-797); (3) one 2^26-point transform forward + inverse, block r on device r, transports p2p and
-copy.  Checks are oracle-free: C(1), C(-1) of the CRT product with Python integers; the transform's round trip and one
+copy, and the split product of two polynomials of 2^25 coefficients (ntt_dist_multiply).  Checks are oracle-free: C(1), C(-1) of the CRT product with Python integers; the transform's round trip and one
 output point evaluated directly."""
 import argparse
 import json
@@ -102,6 +102,29 @@ def main():
             out[f"mdev_ntt2p{lgL}_{transport}_GBps"] = 16 * L / dt / 1e9
             dp.close()
         os.environ.pop("NTT_AMD_DIST_TRANSPORT", None)
+        # the split PRODUCT of two polynomials of L / 2 coefficients (default transport): forward x 2, pointwise, inverse
+        dp = ntt_amd.DistPlan(grp, p, lgL, nd, 0)
+        half = nd // 2
+        dp.multiply(xin[:half], [xin[(r + 1) % half] for r in range(half)], xout)
+        grp.synchronize()
+        with torch.cuda.device(devs[0]):
+            d0 = f"cuda:{devs[0]}"
+            fa = torch.cat([xin[r].to(d0) for r in range(half)])
+            fb = torch.cat([xin[(r + 1) % half].to(d0) for r in range(half)])
+            fab = torch.cat([t.to(d0) for t in xout])
+            for x in (1, p - 1, 0x2545F491 % p):
+                if bench._eval_point_t(torch, fa, x, p) * bench._eval_point_t(torch, fb, x, p) % p != bench._eval_point_t(torch, fab, x, p):
+                    failed.append("split product identity")
+                    break
+            del fa, fb, fab
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            dp.multiply(xin[:half], [xin[(r + 1) % half] for r in range(half)], xout)
+        grp.synchronize()
+        dt = (time.perf_counter() - t0) / args.reps
+        out[f"mdev_product_n2p{lgL - 1}_ms"] = 1e3 * dt
+        out[f"mdev_product_n2p{lgL - 1}_GBps"] = (16 * (L // 2) - 4) / dt / 1e9       # read a, b, write ab
+        dp.close()
     grp.close()
     out["mdev_checks"] = "ok" if not failed else "FAILED: " + ", ".join(failed)
     print(json.dumps(out), flush=True)
