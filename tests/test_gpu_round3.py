@@ -232,13 +232,14 @@ def _largest_prime_below(limit, two_adicity):
     raise AssertionError("no such prime")
 
 
-@pytest.mark.parametrize("n,batch", [(2048, 3), (5000, 2), (40000, 20), (131072, 1), (131072, 19)])
+@pytest.mark.parametrize("n,batch", [(2048, 3), (5000, 2), (20000, 3), (40000, 20), (131072, 1), (131072, 19), (1 << 21, 1)])
 def test_wide_range_kernels_for_primes_below_2pow29(nt, monkeypatch, n, batch):
     """p < 2^29 (8p <= 2^32): the row kernels and forward register column passes keep sums unreduced up to 4p and hand
     out values below 8p (device_ntt.hpp, WIDE; NTT_AMD_WIDE=0 keeps the [0, 2p) kernels).  The reference's three shipped
     primes (main-montgomery.cc:301-306) and the largest prime below 2^29 with 2^18 | p - 1 (the tightest ranges), operands
     of all p - 1 in the first row, Montgomery and Barrett: identical to the [0, 2p) kernels, rows against the oracle
-    (generator 3 is the reference's; for the fourth prime the evaluation identity stands in)."""
+    (generator 3 is the reference's; for the fourth prime the evaluation identity stands in).  Column levels of 16, 32
+    and 64 points and, at n = 2^21, two levels of 32."""
     import torch
     from test_gpu_full_configs import _check_rows
     tight = _largest_prime_below(1 << 29, 18)
