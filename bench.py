@@ -405,6 +405,9 @@ def also_block(args, group, rank, world, local_rank):
                     out["mdev_error"] = f"exit {r.returncode}: {r.stderr[-200:]}"
             except subprocess.TimeoutExpired:
                 out["mdev_error"] = "timeout"
+            group.host_signal("ntt_bench_mdev_done")
+        else:
+            group.host_wait("ntt_bench_mdev_done", args.also_timeout)     # on the host: this rank's GPU stays idle for the child
         group.barrier()
     nfailed = group.sum_over_ranks(float(len(failed)))
     out["checks"] = "ok" if nfailed == 0 else "FAILED on some rank: " + ", ".join(failed)

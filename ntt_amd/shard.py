@@ -68,6 +68,18 @@ class Group:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def host_signal(self, key):
+        """Rank 0 announces `key` through the rendezvous store; see host_wait."""
+        if self.dist is not None:
+            self.dist.distributed_c10d._get_default_store().set(key, "1")
+
+    def host_wait(self, key, seconds=600.0):
+        """Block on the HOST until rank 0 has announced `key` (no collective, so no kernel spins on this rank's GPU
+        meanwhile -- an RCCL barrier would keep one there for as long as rank 0 takes)."""
+        if self.dist is not None:
+            import datetime
+            self.dist.distributed_c10d._get_default_store().wait([key], datetime.timedelta(seconds=seconds))
+
     def close(self):
         if self.dist is not None:
             self.dist.destroy_process_group()

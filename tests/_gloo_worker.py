@@ -34,13 +34,21 @@ def main():
     elapsed = time.perf_counter() - t0
     tmax = g.max_over_ranks(0.05 * (g.rank + 1))
     nunits = g.sum_over_ranks(count)
+    # host-side wait on rank 0 (bench.py: the other ranks idle while rank 0 runs its child process): no collective
+    t1 = time.perf_counter()
+    if g.rank == 0:
+        time.sleep(0.2)
+        g.host_signal("rank0_done")
+    else:
+        g.host_wait("rank0_done", 30.0)
+    waited = g.max_over_ranks(time.perf_counter() - t1)
     gathered = [None] * g.world
     g.dist.all_gather_object(gathered, sums)
     if g.rank == 0:
         merged = {}
         for d in gathered:
             merged.update(d)
-        json.dump({"world": g.world, "tmax": tmax, "nunits": nunits, "elapsed": elapsed,
+        json.dump({"world": g.world, "tmax": tmax, "nunits": nunits, "elapsed": elapsed, "waited": waited,
                    "sums": {str(k): v for k, v in merged.items()}}, open(out_path, "w"))
     g.close()
 

@@ -67,6 +67,7 @@ def test_two_ranks_gloo(tmp_path):
     assert res["world"] == 2 and res["nunits"] == 7
     assert abs(res["tmax"] - 0.10) < 1e-9            # max over ranks, not rank 0's own 0.05
     assert res["elapsed"] >= 0.10                      # the closing barrier waits for the slow rank
+    assert 0.19 <= res["waited"] < 20.0                # host_wait returned once rank 0 had signalled, not before
     n, p = 300, 998244353
     for u in range(7):
         a = (orc.splitmix64_np(0x20250711 + u, n) % np.uint64(p)).astype(np.uint32)
