@@ -215,7 +215,7 @@ struct ntt_dist_plan {
     std::vector<ntt_dist_plan *> part;
     struct GroupSlot {
         ntt::DeviceBuffer held, sendbuf, rowbuf;          // [world][S/world] staging (copy transports), local inverse output
-        ntt::DeviceBuffer spec_a, spec_b, zeros;          // ntt_dist_multiply: the two spectra of this slot, a block of zero padding
+        ntt::DeviceBuffer spec_a, spec_b;                 // ntt_dist_multiply: the two spectra of this slot
         hipStream_t copy_in = nullptr, copy_out = nullptr;
         hipEvent_t start = nullptr, ready = nullptr, done = nullptr, fin = nullptr, out_done = nullptr;
         std::vector<hipEvent_t> ev_in, ev_k;              // per column chunk

@@ -217,6 +217,7 @@ struct DistColArgs {
     int use_scale0;
     uint32_t cols;                       // columns of this slot's piece = S / G (row length of tw)
     uint32_t col0, ncols;                // this launch: columns [col0, col0 + ncols), ncols a multiple of 256
+    int half;                            // forward only: rows >= G / 2 are zero padding (not read; first butterfly stage skipped)
     Roots64<MM> roots;                   // forward or inverse w_64 powers (the G-th root is a stride of them)
 };
 bool launch_dist_col(int kind, bool lazy, int logG, bool inverse, const void *args, const ModParams &mp, hipStream_t s);

@@ -15,23 +15,24 @@
 
 namespace ntt {
 
-template <class MM, bool LAZY, int LOGG, bool INVERSE>
+template <class MM, bool LAZY, int LOGG, bool INVERSE, bool HALF = false>
 __global__ void __launch_bounds__(256) dist_col_kernel(const DistColArgs<MM> a, const ModParams m)
 {
     using O = Ops<MM, LAZY>;
     constexpr int G = 1 << LOGG;
+    static_assert(!(HALF && INVERSE), "zero padding is an input of the forward transform");
     const uint32_t j = a.col0 + blockIdx.x * 256u + threadIdx.x;       // column within this slot's piece
     if (j >= a.col0 + a.ncols) return;                                  // (the host launches whole workgroups; belt and braces)
     uint32_t x[G];
 #pragma unroll
-    for (int i1 = 0; i1 < G; ++i1) x[i1] = a.in[i1][j];
+    for (int i1 = 0; i1 < G; ++i1) x[i1] = (HALF && i1 >= G / 2) ? 0u : a.in[i1][j];   // HALF: the upper blocks are not read at all
     if constexpr (INVERSE) {
         // canonical inputs (the local inverse transform stores canonical residues); row 0 carries G^-1
         x[0] = a.use_scale0 ? O::mul_tw(x[0], a.scale0, m) : x[0];
 #pragma unroll
         for (int k1 = 1; k1 < G; ++k1) x[k1] = O::mul_tw(x[k1], a.tw[(size_t)k1 * a.cols + j], m);
     }
-    reg_ntt<MM, LAZY, LOGG, false, true>(x, a.roots, m);                // loose outputs
+    reg_ntt<MM, LAZY, LOGG, HALF, true>(x, a.roots, m);                 // loose outputs
     if constexpr (!INVERSE) {
         x[0] = O::tighten(x[0], m);
 #pragma unroll
@@ -48,6 +49,7 @@ static bool launch_dist_l(int logG, bool inverse, const DistColArgs<MM> &a, cons
 #define NTT_DIST_CASE(LG)                                                                                         \
     case LG:                                                                                                      \
         if (inverse) hipLaunchKernelGGL((dist_col_kernel<MM, LAZY, LG, true>), grid, block, 0, s, a, mp);         \
+        else if (a.half) hipLaunchKernelGGL((dist_col_kernel<MM, LAZY, LG, false, true>), grid, block, 0, s, a, mp); \
         else hipLaunchKernelGGL((dist_col_kernel<MM, LAZY, LG, false>), grid, block, 0, s, a, mp);                \
         return true;
     switch (logG) {

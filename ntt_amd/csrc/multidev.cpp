@@ -448,7 +448,7 @@ void group_dist_plan_release(ntt_dist_plan *dp)
         for (hipEvent_t e : gs.ev_in) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : gs.ev_k) if (e) (void)hipEventDestroy(e);
         gs.held.release(); gs.sendbuf.release(); gs.rowbuf.release();
-        gs.spec_a.release(); gs.spec_b.release(); gs.zeros.release();
+        gs.spec_a.release(); gs.spec_b.release();
     }
     dp->gslot.clear();
     if (!dp->comms.empty())
@@ -539,7 +539,7 @@ int group_dist_plan_create(ntt_ctx *g, uint32_t p, int lgL, int world, int kind,
 
 // the column kernel of slot h over columns [col0, col0 + ncols) of its piece
 template <class MM>
-static int launch_slot_colpass(ntt_dist_plan *dp, int h, bool inverse, const uint32_t *const *src, uint32_t *const *dst,
+static int launch_slot_colpass(ntt_dist_plan *dp, int h, bool inverse, bool half, const uint32_t *const *src, uint32_t *const *dst,
                                uint32_t col0, uint32_t ncols, hipStream_t stream)
 {
     ntt_dist_plan *part = dp->part[(size_t)h];
@@ -557,6 +557,7 @@ static int launch_slot_colpass(ntt_dist_plan *dp, int h, bool inverse, const uin
     a.cols = cols;
     a.col0 = col0;
     a.ncols = ncols;
+    a.half = (half && !inverse) ? 1 : 0;
     std::memcpy(&a.roots, (inverse ? cp->iroots : cp->roots).data(), sizeof(a.roots));
     int lgG = 0;
     while ((1 << lgG) < G) ++lgG;
@@ -568,7 +569,9 @@ static int launch_slot_colpass(ntt_dist_plan *dp, int h, bool inverse, const uin
 // Inverse: the reverse, scaled by L^-1.  Everything is queued; ntt_ctx_synchronize(group) waits for it.
 // scrambled: the local transforms leave / take the spectrum in the engine's own order (no permutation pass): the two
 // halves of ntt_dist_multiply.
-static int group_dist_run(ntt_dist_plan *dp, const uint32_t *const *in, uint32_t *const *out, bool inverse, bool scrambled = false)
+// half (forward only): the blocks of slots >= world / 2 are zero padding -- never read, never exchanged.
+static int group_dist_run(ntt_dist_plan *dp, const uint32_t *const *in, uint32_t *const *out, bool inverse, bool scrambled = false,
+                          bool half = false)
 {
     ntt_ctx *g = dp->ctx;
     const int G = dp->world;
@@ -576,6 +579,7 @@ static int group_dist_run(ntt_dist_plan *dp, const uint32_t *const *in, uint32_t
     const int C = dp->chunks;
     const uint32_t cc = cols / (uint32_t)C;
     const int kind = dp->part[0]->colp->kind;
+    const int nz = (half && !inverse) ? G / 2 : G;            // rows (= blocks) that hold data
     // every slot starts behind the end of the previous call on EVERY slot: peers are about to write into its arrays
     for (int s = 0; s < G; ++s) {
         HIP_TRY(hipSetDevice(g->sub[(size_t)s]->device));
@@ -620,8 +624,8 @@ static int group_dist_run(ntt_dist_plan *dp, const uint32_t *const *in, uint32_t
                 HIP_TRY(hipSetDevice(g->sub[(size_t)h]->device));
                 uint32_t *held = static_cast<uint32_t *>(gs.held.ptr);
                 for (int i = 0; i < G; ++i) {
-                    RCCL_TRY(rc_lib, rc_lib->Send(rows[(size_t)h] + (size_t)i * cols + c0, cc, Rccl::kUint32, i, dp->comms[(size_t)h], gs.copy_in));
-                    RCCL_TRY(rc_lib, rc_lib->Recv(held + (size_t)i * cols + c0, cc, Rccl::kUint32, i, dp->comms[(size_t)h], gs.copy_in));
+                    if (h < nz) RCCL_TRY(rc_lib, rc_lib->Send(rows[(size_t)h] + (size_t)i * cols + c0, cc, Rccl::kUint32, i, dp->comms[(size_t)h], gs.copy_in));
+                    if (i < nz) RCCL_TRY(rc_lib, rc_lib->Recv(held + (size_t)i * cols + c0, cc, Rccl::kUint32, i, dp->comms[(size_t)h], gs.copy_in));
                 }
             }
             RCCL_TRY(rc_lib, rc_lib->GroupEnd());
@@ -635,19 +639,19 @@ static int group_dist_run(ntt_dist_plan *dp, const uint32_t *const *in, uint32_t
             const uint32_t *src[kMaxDistWorld];
             uint32_t *dst[kMaxDistWorld];
             for (int i = 0; i < G; ++i) {
-                src[i] = dp->transport == 0 ? rows[(size_t)i] + (size_t)h * cols : held + (size_t)i * cols;
+                src[i] = i >= nz ? nullptr : dp->transport == 0 ? rows[(size_t)i] + (size_t)h * cols : held + (size_t)i * cols;
                 dst[i] = dp->transport >= 2 ? sendbuf + (size_t)i * cols : out[i] + (size_t)h * cols;
             }
             if (dp->transport == 1 || dp->transport == 2)   // exchange in: this chunk's slice of every peer's row
-                for (int i = 0; i < G; ++i)
+                for (int i = 0; i < nz; ++i)
                     HIP_TRY(hipMemcpyPeerAsync(held + (size_t)i * cols + c0, c->device, rows[(size_t)i] + (size_t)h * cols + c0,
                                                g->sub[(size_t)i]->device, (size_t)cc * sizeof(uint32_t), gs.copy_in));
             if (dp->transport >= 1) {
                 HIP_TRY(hipEventRecord(gs.ev_in[(size_t)ch], gs.copy_in));
                 HIP_TRY(hipStreamWaitEvent(sh, gs.ev_in[(size_t)ch], 0));
             }
-            const int rc = kind == NTT_MODMUL_MONTGOMERY ? launch_slot_colpass<Mont32>(dp, h, inverse, src, dst, c0, cc, sh)
-                                                         : launch_slot_colpass<Barrett32>(dp, h, inverse, src, dst, c0, cc, sh);
+            const int rc = kind == NTT_MODMUL_MONTGOMERY ? launch_slot_colpass<Mont32>(dp, h, inverse, half, src, dst, c0, cc, sh)
+                                                         : launch_slot_colpass<Barrett32>(dp, h, inverse, half, src, dst, c0, cc, sh);
             if (rc) return rc;
             if (dp->transport >= 2) {                       // exchange out: row k1 of this chunk to slot k1
                 HIP_TRY(hipEventRecord(gs.ev_k[(size_t)ch], sh));
@@ -714,19 +718,14 @@ static int group_dist_multiply(ntt_dist_plan *dp, const uint32_t *const *a, cons
         int rc = gs.spec_a.ensure(bytes);
         if (!rc) rc = gs.spec_b.ensure(bytes);
         if (rc) return rc;
-        if (r >= G / 2 && !gs.zeros.ptr) {                   // the zero padding of both operands, written once
-            if ((rc = gs.zeros.ensure(bytes))) return rc;
-            HIP_TRY(hipMemsetAsync(gs.zeros.ptr, 0, bytes, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));        // peers read it from their own streams: complete before anyone can
-        }
-        ina[(size_t)r] = r < G / 2 ? a[r] : static_cast<const uint32_t *>(gs.zeros.ptr);
-        inb[(size_t)r] = r < G / 2 ? b[r] : static_cast<const uint32_t *>(gs.zeros.ptr);
+        ina[(size_t)r] = r < G / 2 ? a[r] : nullptr;         // the upper half of both operands is zero padding: not read
+        inb[(size_t)r] = r < G / 2 ? b[r] : nullptr;
         spa[(size_t)r] = static_cast<uint32_t *>(gs.spec_a.ptr);
         spb[(size_t)r] = static_cast<uint32_t *>(gs.spec_b.ptr);
         spa_c[(size_t)r] = spa[(size_t)r];
     }
-    int rc = group_dist_run(dp, ina.data(), spa.data(), false, true);
-    if (!rc) rc = group_dist_run(dp, inb.data(), spb.data(), false, true);
+    int rc = group_dist_run(dp, ina.data(), spa.data(), false, true, true);
+    if (!rc) rc = group_dist_run(dp, inb.data(), spb.data(), false, true, true);
     if (rc) return rc;
     for (int r = 0; r < G; ++r) {                            // behind the slot's own local transforms (stream order)
         ntt_ctx *c = g->sub[(size_t)r];
