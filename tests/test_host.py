@@ -260,3 +260,16 @@ else:
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.strip() == "status 4"          # NTT_ERR_NOMEM
+
+
+def test_bench_prime_search_matches_trial_division():
+    """bench.py's RNS prime list (Miller-Rabin) is the one the GPU tests build by trial division (SURVEY 8d, configs[3]:
+    the 32 smallest primes above 2^30 with p = 1 mod 2^17)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    want, step, p = [], 1 << 17, (1 << 30) + 1
+    while len(want) < 32:
+        if all(p % q for q in range(3, int(p ** 0.5) + 1, 2)):
+            want.append(p)
+        p += step
+    assert bench.rns_primes(32, 17, 1 << 30) == want
