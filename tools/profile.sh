@@ -20,7 +20,7 @@ for PASS in "FETCH_SIZE" "WRITE_SIZE" \
             "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" \
             "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
     NAME=$(echo $PASS | cut -d' ' -f1)
-    timeout -s KILL 300 rocprofv3 --pmc $PASS --output-format csv -d "$OUT/pmc_$NAME" -- $BENCH --steps 1 --warmup 1 \
+    timeout -s KILL 300 rocprofv3 --pmc $PASS --output-format csv -d "$OUT/pmc_$NAME" -- $BENCH --steps 1 --warmup 1 --settle-seconds 0 \
         > "$OUT/pmc_$NAME.log" 2>&1 || { echo "pmc pass $NAME failed"; tail -5 "$OUT/pmc_$NAME.log"; exit 1; }
     echo "pmc pass $NAME done"
 done
