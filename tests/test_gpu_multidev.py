@@ -382,3 +382,41 @@ def test_group_dist_multiply_2pow26_over_8_slots(nt):
     assert torch.equal(got[:L - 1], want)
     plan.close()
     single.close()
+
+
+@pytest.mark.parametrize("devices", ["0,0,0,0", "0,0"])
+def test_cli_on_a_multi_device_context(nt, nttdata, tmp_path, devices):
+    """ntt_cli --devices: the rank layout of main-mpi.cc:642-819 in one process -- cases with a 32-bit modulus on slot 0
+    (the other slots idle, :710-738), the 51-bit case with its four CRT primes partitioned over the slots and the slice
+    exchange (:739-797).  The reference's cases 0 and 1 against their golden outputs, a synthetic 51-bit case against
+    the CRT oracle; verdict lines, latency lines and written files as the single-device harness."""
+    import os
+    import subprocess
+    data, out = tmp_path / "nttdata", tmp_path / "files"
+    data.mkdir()
+    out.mkdir()
+    for cid in (0, 1):
+        n, p, a, b, ab = nttdata[cid]
+        with open(data / f"{cid}.in", "w") as f:
+            f.write(f"{n} {p}\n" + "".join(f"{v} " for v in a) + "\n" + "".join(f"{v} " for v in b))
+        with open(data / f"{cid}.out", "w") as f:
+            f.write("".join(f"{v} " for v in ab))
+    n4 = 3001
+    rng = np.random.default_rng(len(devices))
+    a4 = rng.integers(0, P64, size=n4, dtype=np.uint64)
+    b4 = rng.integers(0, P64, size=n4, dtype=np.uint64)
+    ab4, _ = orc.poly_multiply_crt(a4, b4, P64, threads=4)
+    with open(data / "2.in", "w") as f:
+        f.write(f"{n4} {P64}\n" + "".join(f"{v} " for v in a4) + "\n" + "".join(f"{v} " for v in b4))
+    with open(data / "2.out", "w") as f:
+        f.write("".join(f"{v} " for v in ab4))
+    exe = os.path.join(os.path.dirname(nt.__file__), "ntt_cli")
+    r = subprocess.run([exe, "--data", str(data), "--out", str(out), "--begin", "0", "--end", "2", "--epochs", "3",
+                        "--devices", devices], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("多项式乘法结果正确") == 3 and "多项式乘法结果错误" not in r.stdout
+    assert any(l.startswith(f"average latency for n = {n4} p = {P64} : ") for l in r.stdout.split("\n"))
+    assert np.array_equal(np.loadtxt(out / "2.out", dtype=np.uint64), ab4)
+    assert np.array_equal(np.loadtxt(out / "1.out", dtype=np.uint64).astype(np.uint32), nttdata[1][4])
+    r = subprocess.run([exe, "--devices", "0,x"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2
