@@ -83,6 +83,13 @@ void poly_multiply(int *a, int *b, int *ab, int n, int p);
  *     slot: ntt_ctx_device(ctx, slot, &slot_ctx, &device) hands out the slot's single-device context, owned by ctx. */
 int ntt_ctx_create(const int *device_ids, int ndev, ntt_ctx **out_ctx);
 int ntt_ctx_device_count(const ntt_ctx *ctx);
+/* Products whose operands already live where they are multiplied: a plan of a multi-device context, one array triple per
+ * slot -- a[s], b[s] are [count[s]][n], ab[s] is [count[s]][ab_stride], on (or reachable from) the device of slot s;
+ * count[s] <= ceil(batch / slots), 0 for a slot without work.  The batch-per-GPU layout of BASELINE.json configs[1] /
+ * north_star item (4) for ONE process (ntt_poly_multiply_batched on such a plan takes one array and slices it by
+ * ntt_partition instead); no exchange, one host thread per slot.  Queued for device arrays. */
+int ntt_poly_multiply_batched_slots(ntt_plan *plan, const uint32_t *const *a, const uint32_t *const *b, uint32_t *const *ab,
+                                    size_t ab_stride, const int *count);
 /* The sharding rule every multi-device call uses, as a function: units [*start, *start + *count) of `total_units` belong
  * to slot (or rank) `rank` of `world` -- ceil(total / world) units each, the last ones fewer or none.  It is the
  * reference's rule for its four primes, mods_per_process = ceil(4 / size), start = rank * mods_per_process,

@@ -43,7 +43,7 @@ EXPORTED_SYMBOLS = (
     "ntt_plan64_create", "ntt_plan64_destroy", "ntt_plan64_length", "ntt_poly_multiply64_batched",
     "ntt_crt_residue_multiply", "ntt_crt_merge", "ntt_dist_plan_create", "ntt_dist_plan_destroy",
     "ntt_dist_colpass", "ntt_dist_local", "ntt_dist_local_length",
-    "ntt_ctx_device_count", "ntt_ctx_device", "ntt_partition", "ntt_dist_forward", "ntt_dist_inverse", "ntt_dist_plan_transport", "ntt_dist_multiply",
+    "ntt_ctx_device_count", "ntt_ctx_device", "ntt_partition", "ntt_poly_multiply_batched_slots", "ntt_dist_forward", "ntt_dist_inverse", "ntt_dist_plan_transport", "ntt_dist_multiply",
     "ntt_ctx_enable_kernel_timing", "ntt_ctx_kernel_timing_select", "ntt_ctx_kernel_timing_stride", "ntt_ctx_kernel_time", "ntt_last_error", "ntt_read_case",
     "ntt_check_case", "ntt_write_case", "ntt_poly_multiply_stream", "ntt_host_alloc", "ntt_host_free",
     "ntt_pack_case", "ntt_read_case_bin", "ntt_check_case_bin", "ntt_write_case_bin",
@@ -98,6 +98,7 @@ def _load():
     lib.ntt_dist_local_length.argtypes = [vp]
     lib.ntt_ctx_device_count.argtypes = [vp]
     lib.ntt_partition.argtypes = [C.c_long, i32, i32, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    lib.ntt_poly_multiply_batched_slots.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), sz, C.POINTER(i32)]
     lib.ntt_ctx_device.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32)]
     lib.ntt_dist_forward.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.ntt_dist_inverse.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
@@ -341,6 +342,21 @@ class Plan:
         _check(_lib.ntt_poly_multiply_batched(self._h, _ptr(a, np.uint32, batch * self.n), _ptr(b, np.uint32, batch * self.n),
                                               _ptr(out, np.uint32, need_out), out_stride, batch))
         return out
+
+    def multiply_slots(self, a_list, b_list, out_list, counts, out_stride=None):
+        """Plan of a multi-device context: slot s multiplies its own arrays a_list[s], b_list[s] ([counts[s], n]) into
+        out_list[s] (``ntt_poly_multiply_batched_slots``); None for a slot without work."""
+        nd = len(counts)
+        if out_stride is None:
+            out_stride = 2 * self.n - 1
+
+        def arr(xs, need_of):
+            return (C.c_void_p * nd)(*[_ptr(x, np.uint32, need_of(c)).value if c else None for x, c in zip(xs, counts)])
+        ca = (C.c_int * nd)(*[int(c) for c in counts])
+        _check(_lib.ntt_poly_multiply_batched_slots(
+            self._h, arr(a_list, lambda c: c * self.n), arr(b_list, lambda c: c * self.n),
+            arr(out_list, lambda c: (c - 1) * out_stride + 2 * self.n - 1), out_stride, ca))
+        return out_list
 
     def multiply_noalloc(self, a, b, out, batch, out_stride=None):
         """``ntt_poly_multiply_batched_noalloc``: device tensors only, intermediates in the library's static

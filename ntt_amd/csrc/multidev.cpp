@@ -799,6 +799,30 @@ try {
 }
 NTT_CATCH_STATUS
 
+int ntt_poly_multiply_batched_slots(ntt_plan *pl, const uint32_t *const *a, const uint32_t *const *b, uint32_t *const *ab,
+                                    size_t ab_stride, const int *count)
+try {
+    if (!pl || !a || !b || !ab || !count) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched_slots: null argument");
+    if (pl->shard.empty()) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched_slots: needs a plan made from a multi-device context");
+    if (pl->negacyclic) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched_slots: not for negacyclic plans");
+    ntt_ctx *g = pl->ctx;
+    const int nd = (int)g->sub.size();
+    for (int s = 0; s < nd; ++s) {
+        if (count[s] < 0 || count[s] > pl->shard[(size_t)s]->batch)
+            return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched_slots: count[" + std::to_string(s) + "] exceeds the slot's share of the plan's capacity (ceil(batch / slots))");
+        if (count[s] && (!a[s] || !b[s] || !ab[s])) return fail(NTT_ERR_INVALID, "ntt_poly_multiply_batched_slots: null array for a slot with work");
+        int rc;
+        if (count[s] && ((rc = check_reachable(g, a[s], s, "ntt_poly_multiply_batched_slots: a")) || (rc = check_reachable(g, b[s], s, "ntt_poly_multiply_batched_slots: b")) ||
+                         (rc = check_reachable(g, ab[s], s, "ntt_poly_multiply_batched_slots: ab"))))
+            return rc;
+    }
+    return for_each_slot(nd, [&](int s) -> int {
+        if (!count[s]) return NTT_OK;
+        return ntt_poly_multiply_batched(pl->shard[(size_t)s], a[s], b[s], ab[s], ab_stride, count[s]);
+    });
+}
+NTT_CATCH_STATUS
+
 int ntt_dist_multiply(ntt_dist_plan *dp, const uint32_t *const *a, const uint32_t *const *b, uint32_t *const *ab)
 try {
     const char *who = "ntt_dist_multiply";

@@ -420,3 +420,47 @@ def test_cli_on_a_multi_device_context(nt, nttdata, tmp_path, devices):
     assert np.array_equal(np.loadtxt(out / "1.out", dtype=np.uint64).astype(np.uint32), nttdata[1][4])
     r = subprocess.run([exe, "--devices", "0,x"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2
+
+
+def test_group_multiply_with_arrays_per_slot(nt):
+    """ntt_poly_multiply_batched_slots: every slot multiplies arrays of its own (the batch-per-GPU layout for one
+    process), uneven counts and a slot without work; rows against the oracle, capacity and null checks."""
+    import torch
+    p, n, ndev = 998244353, 40000, 3
+    rng = np.random.default_rng(17)
+    g = nt.Context(devices=[0] * ndev)
+    plan = g.plan(p, n, 12)                                   # 4 products per slot
+    counts = [4, 0, 3]
+    host, dev_a, dev_b, outs = [], [], [], []
+    for c in counts:
+        a = rng.integers(0, p, size=(max(c, 1), n), dtype=np.int64).astype(np.uint32)
+        b = rng.integers(0, p, size=(max(c, 1), n), dtype=np.int64).astype(np.uint32)
+        host.append((a, b))
+        dev_a.append(torch.from_numpy(a.view(np.int32)).cuda() if c else None)
+        dev_b.append(torch.from_numpy(b.view(np.int32)).cuda() if c else None)
+        outs.append(torch.full((c, 2 * n - 1), -1, dtype=torch.int32, device="cuda") if c else None)
+    torch.cuda.synchronize()
+    plan.multiply_slots(dev_a, dev_b, outs, counts)
+    g.synchronize()
+    for s, c in enumerate(counts):
+        for r in range(c):
+            assert np.array_equal(outs[s][r].cpu().numpy().view(np.uint32), orc.poly_multiply(host[s][0][r], host[s][1][r], p)), (s, r)
+    # host arrays per slot work as well (each slot stages its own)
+    houts = [np.zeros((c, 2 * n - 1), dtype=np.uint32) if c else None for c in counts]
+    plan.multiply_slots([h[0] if c else None for h, c in zip(host, counts)], [h[1] if c else None for h, c in zip(host, counts)], houts, counts)
+    for s, c in enumerate(counts):
+        if c:
+            assert np.array_equal(houts[s], outs[s].cpu().numpy().view(np.uint32))
+    small = g.plan(p, n, 9)                                   # 3 products per slot
+    with pytest.raises(nt.NttError) as e:
+        small.multiply_slots(dev_a, dev_b, outs, counts)      # 4 on slot 0: more than ceil(9 / 3)
+    assert e.value.code == nt.ERR_INVALID
+    small.close()
+    single = nt.Context(0)
+    sp = single.plan(p, n, 4)
+    with pytest.raises(nt.NttError):
+        sp.multiply_slots([dev_a[0]], [dev_b[0]], [outs[0]], [4])
+    sp.close()
+    single.close()
+    plan.close()
+    g.close()

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--devices", default="0,0")
     ap.add_argument("--lgL", type=int, default=26)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512, help="products per slot of the batch-per-device workload")
     args = ap.parse_args()
     devs = [int(x) for x in args.devices.split(",")]
     import torch
@@ -36,6 +37,40 @@ def main():
     failed = []
     grp = ntt_amd.Context(devices=devs)
     nd = len(devs)
+
+    # (1) the headline workload, batch per device (BASELINE.json configs[1]): every slot multiplies B products of n = 2^17
+    # held in its own HBM; one process, one host thread per slot, no exchange
+    n, p, B = 131072, 998244353, args.batch
+    plan = grp.plan(p, n, B * nd)
+    da, db, dab = [], [], []
+    for r, d in enumerate(devs):
+        with torch.cuda.device(d):
+            gen = torch.Generator(device="cuda")
+            gen.manual_seed(1 + r)
+            da.append(torch.randint(0, p, (B, n), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32))
+            db.append(torch.randint(0, p, (B, n), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32))
+            dab.append(torch.zeros((B, 2 * n), dtype=torch.int32, device="cuda"))
+            torch.cuda.synchronize()
+    counts = [B] * nd
+    for _ in range(3):
+        plan.multiply_slots(da, db, dab, counts, out_stride=2 * n)
+    grp.synchronize()
+    for r, d in enumerate(devs):                                # A(x) B(x) = AB(x) on the last row of every slot
+        with torch.cuda.device(d):
+            for x in (1, 0x2545F491 % p):
+                if bench._eval_point_t(torch, da[r][B - 1].contiguous(), x, p, blk=1 << 12) * bench._eval_point_t(torch, db[r][B - 1].contiguous(), x, p, blk=1 << 12) % p != \
+                        bench._eval_point_t(torch, torch.cat([dab[r][B - 1, :2 * n - 1], torch.zeros(1, dtype=torch.int32, device="cuda")]), x, p, blk=1 << 12):
+                    failed.append(f"batch identity (slot {r})")
+                    break
+    t0 = time.perf_counter()
+    for _ in range(args.reps * 2):
+        plan.multiply_slots(da, db, dab, counts, out_stride=2 * n)
+    grp.synchronize()
+    dt = (time.perf_counter() - t0) / (args.reps * 2)
+    out["mdev_batch_products_per_s"] = nd * B / dt
+    out["mdev_batch_per_slot"] = B
+    plan.close()
+    del da, db, dab
 
     # (2) large-modulus product, prime per device
     n, p64 = 131072, 1337006139375617
