@@ -393,7 +393,7 @@ def also_block(args, group, rank, world, local_rank):
             try:
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mdev_bench.py"), "--devices",
                                     ",".join(str(d) for d in devs)], capture_output=True, text=True,
-                                   timeout=max(20.0, args.also_timeout / 2))
+                                   timeout=max(20.0, args.also_timeout / 3))
                 lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
                 if lines:
                     md = json.loads(lines[-1])
@@ -405,6 +405,28 @@ def also_block(args, group, rank, world, local_rank):
                     out["mdev_error"] = f"exit {r.returncode}: {r.stderr[-200:]}"
             except subprocess.TimeoutExpired:
                 out["mdev_error"] = "timeout"
+            # (e) and once more with ONE PROCESS PER GPU inside the library: ntt_comm (comm.cpp), the communicator a C++
+            # host program shaped like main-mpi.cc would use -- RCCL joined by the library itself when the ranks own
+            # GPUs, the host program's all-to-all on host memory otherwise.  A child JOB of `world` ranks, same reason
+            try:
+                port = int(os.environ.get("MASTER_PORT", "29511")) + 37
+                r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                                    "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                    os.path.join(ROOT, "tools", "comm_bench.py"), "--backend", "nccl" if on_device else "gloo"],
+                                   capture_output=True, text=True, timeout=max(30.0, args.also_timeout / 3),
+                                   env={k: v for k, v in os.environ.items() if k not in
+                                        ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_PORT",
+                                         "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS")})
+                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if lines:
+                    cj = json.loads(lines[-1])
+                    out.update({k: v for k, v in cj.items() if k.startswith("comm_")})
+                    if cj.get("comm_checks") != "ok":
+                        failed.append("in-library process-per-GPU communicator")
+                else:
+                    out["comm_error"] = f"exit {r.returncode}: {r.stderr[-200:]}"
+            except subprocess.TimeoutExpired:
+                out["comm_error"] = "timeout"
             group.host_signal("ntt_bench_mdev_done")
         else:
             group.host_wait("ntt_bench_mdev_done", args.also_timeout)     # on the host: this rank's GPU stays idle for the child
@@ -419,7 +441,8 @@ def kernel_source_stamp():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "ntt_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):            # the device code: kernels and the headers they include
+        # the device code: kernels and the headers they include (engine.hpp, rccl_dl.hpp are host-only: no kernel sees them)
+        if f.endswith((".hip", ".hpp")) and f not in ("engine.hpp", "rccl_dl.hpp"):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

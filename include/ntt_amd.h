@@ -281,6 +281,46 @@ int ntt_dist_plan_transport(const ntt_dist_plan *plan, int *transport, int *chun
  * between the forward and the inverse transform.  a, b are not modified; queued like ntt_dist_forward. */
 int ntt_dist_multiply(ntt_dist_plan *plan, const uint32_t *const *a, const uint32_t *const *b, uint32_t *const *ab);
 
+/* ---- one process per GPU: the exchanges for a host program that keeps the reference's MPI shape ----------------
+ * main-mpi.cc is one process per rank (:645-649 MPI_Init / rank / size, :685-688 the case reaches every rank by
+ * MPI_Bcast, :657-660 rank r owns ceil(4 / size) primes, :770 multiplies their residues, :772-791 MPI_Send / MPI_Recv
+ * of the residue polynomials to rank 0, :793-796 rank 0 merges).  A program that stays that way gives every rank an
+ * ordinary single-device context on its GPU and ONE communicator; the collective calls below (every rank makes the
+ * same calls in the same order, as with MPI collectives) then run what a multi-device context runs in one process,
+ * with the exchange carried by
+ *   ntt_comm_create_rccl   RCCL: grouped ncclSend / ncclRecv on device arrays over xGMI, librccl opened with dlopen.
+ *                          ntt_comm_rccl_id on one rank makes the NTT_COMM_ID_BYTES-byte id, the host program hands it
+ *                          to the others (MPI_Bcast), then every rank calls ntt_comm_create_rccl (itself collective).
+ *                          One rank per device (RCCL refuses two ranks on one GPU).  The split transform is cut into
+ *                          4 column chunks: the exchange of chunk c + 1 runs beside the column kernel of chunk c.
+ *                          Exercised by us at world = 1 only (one GPU): parity unpinned on real links.
+ *   ntt_comm_create_host   the host program's own all-to-all on HOST memory (ntt_alltoall_fn; with MPI one line:
+ *                          MPI_Alltoall(send, bytes, MPI_BYTE, recv, bytes, MPI_BYTE, comm)); the library stages
+ *                          through pinned buffers and calls it from the calling thread, synchronously.  Works for
+ *                          ranks that share a GPU (how tests/test_gpu_comm.py runs 2 and 4 ranks on one).
+ * ntt_comm_dist_forward / _inverse: the split transform of ntt_dist_plan_create(ctx, p, lgL, world, rank, ...) on
+ *   this rank's block (device arrays of S = L / world words, in != out, in is not modified), same layouts as
+ *   ntt_dist_forward / ntt_dist_inverse above; world <= 16.  Queued on the context's stream in RCCL mode
+ *   (ntt_ctx_synchronize waits); complete on return in host mode.
+ * ntt_comm_crt_multiply: the large-modulus product of ntt_crt_multiply with prime k on rank k / ceil(4 / world)
+ *   (main-mpi.cc:657-660), slice h of every residue polynomial sent to rank h, merged there, and the merged slices
+ *   gathered: a, b ([n] u64, host or device, the same on every rank as after the reference's MPI_Bcast), ab ([2n - 1]
+ *   u64, host or device) complete on EVERY rank (the reference: rank 0 only).  Device ab in RCCL mode: queued.
+ * Calls on one communicator are serialised; a communicator must be destroyed before its context. */
+typedef struct ntt_comm ntt_comm;
+#define NTT_COMM_ID_BYTES 128
+/* send / recv: world blocks of bytes_per_rank bytes each; block h of send goes to rank h, block s of recv comes from
+ * rank s.  Return 0 on success (anything else fails the collective call with NTT_ERR_IO). */
+typedef int (*ntt_alltoall_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank);
+int ntt_comm_rccl_id(void *id /* NTT_COMM_ID_BYTES */);
+int ntt_comm_create_rccl(ntt_ctx *ctx, const void *id, int world, int rank, ntt_comm **out_comm);
+int ntt_comm_create_host(ntt_ctx *ctx, ntt_alltoall_fn alltoall, void *user, int world, int rank, ntt_comm **out_comm);
+int ntt_comm_destroy(ntt_comm *comm);
+int ntt_comm_size(const ntt_comm *comm, int *world, int *rank, int *kind /* 0 host, 1 rccl */);
+int ntt_comm_dist_forward(ntt_comm *comm, ntt_dist_plan *plan, const uint32_t *in, uint32_t *out);
+int ntt_comm_dist_inverse(ntt_comm *comm, ntt_dist_plan *plan, const uint32_t *in, uint32_t *out);
+int ntt_comm_crt_multiply(ntt_comm *comm, const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p64);
+
 /* Per-kernel timing (HIP events on the context's stream) for bench.py's roofline block.
  * With timing enabled every kernel launch is bracketed by events; ntt_ctx_kernel_time returns
  * the accumulated milliseconds and launch count of kernel `index` (0 .. count-1) and its name;

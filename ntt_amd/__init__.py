@@ -44,6 +44,7 @@ EXPORTED_SYMBOLS = (
     "ntt_crt_residue_multiply", "ntt_crt_merge", "ntt_dist_plan_create", "ntt_dist_plan_destroy",
     "ntt_dist_colpass", "ntt_dist_local", "ntt_dist_local_length",
     "ntt_ctx_device_count", "ntt_ctx_device", "ntt_partition", "ntt_poly_multiply_batched_slots", "ntt_dist_forward", "ntt_dist_inverse", "ntt_dist_plan_transport", "ntt_dist_multiply",
+    "ntt_comm_rccl_id", "ntt_comm_create_rccl", "ntt_comm_create_host", "ntt_comm_destroy", "ntt_comm_size", "ntt_comm_dist_forward", "ntt_comm_dist_inverse", "ntt_comm_crt_multiply",
     "ntt_ctx_enable_kernel_timing", "ntt_ctx_kernel_timing_select", "ntt_ctx_kernel_timing_stride", "ntt_ctx_kernel_time", "ntt_last_error", "ntt_read_case",
     "ntt_check_case", "ntt_write_case", "ntt_poly_multiply_stream", "ntt_host_alloc", "ntt_host_free",
     "ntt_pack_case", "ntt_read_case_bin", "ntt_check_case_bin", "ntt_write_case_bin",
@@ -54,6 +55,11 @@ class NttError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"ntt_amd error {code}: {msg}")
         self.code = code
+
+
+# ntt_alltoall_fn (include/ntt_amd.h): int (*)(void *user, const void *send, void *recv, size_t bytes_per_rank)
+ALLTOALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+COMM_ID_BYTES = 128
 
 
 def _load():
@@ -104,6 +110,14 @@ def _load():
     lib.ntt_dist_inverse.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.ntt_dist_plan_transport.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.ntt_dist_multiply.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.ntt_comm_rccl_id.argtypes = [vp]
+    lib.ntt_comm_create_rccl.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+    lib.ntt_comm_create_host.argtypes = [vp, ALLTOALL_FN, vp, i32, i32, C.POINTER(vp)]
+    lib.ntt_comm_destroy.argtypes = [vp]
+    lib.ntt_comm_size.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.ntt_comm_dist_forward.argtypes = [vp, vp, vp, vp]
+    lib.ntt_comm_dist_inverse.argtypes = [vp, vp, vp, vp]
+    lib.ntt_comm_crt_multiply.argtypes = [vp, vp, vp, vp, i32, u64]
     lib.ntt_ctx_enable_kernel_timing.argtypes = [vp, i32]
     lib.ntt_ctx_kernel_timing_select.argtypes = [vp, i32]
     lib.ntt_ctx_kernel_timing_stride.argtypes = [vp, i32]
@@ -520,6 +534,90 @@ class DistPlan:
         arr = lambda xs: (C.c_void_p * self.world)(*[_ptr(x, np.uint32, self.local_length).value if x is not None else None for x in xs])
         _check(_lib.ntt_dist_multiply(self._h, arr(list(a_blocks) + pad), arr(list(b_blocks) + pad), self._blocks(ab_blocks)))
         return ab_blocks
+
+
+class Comm:
+    """One rank's communicator of a process-per-GPU job (``ntt_comm``, include/ntt_amd.h): the exchanges of the split
+    transform and of the prime-per-rank large-modulus product inside the library, for a host program shaped like the
+    reference's MPI driver (main-mpi.cc:645-797).  Every rank makes the same calls in the same order.
+
+    ``Comm.rccl(ctx, id, world, rank)``: RCCL on device arrays (``Comm.rccl_id()`` on one rank, the bytes handed to
+    the others by the host program); ``Comm.host(ctx, alltoall, world, rank)``: ``alltoall(send, recv)`` is the host
+    program's own all-to-all over two uint8 numpy views of pinned host memory shaped [world, bytes_per_rank] (row h of
+    send goes to rank h, row s of recv comes from rank s) -- MPI_Alltoall, or torch.distributed over gloo."""
+
+    def __init__(self, ctx, handle, keep=None):
+        self.ctx, self._h, self._keep = ctx, handle, keep
+        w, r, k = C.c_int(), C.c_int(), C.c_int()
+        _check(_lib.ntt_comm_size(handle, C.byref(w), C.byref(r), C.byref(k)))
+        self.world, self.rank, self.kind = w.value, r.value, ("rccl" if k.value else "host")
+        ctx._plans.add(self)                 # closed with (before) its context
+
+    @staticmethod
+    def rccl_id():
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _check(_lib.ntt_comm_rccl_id(buf))
+        return buf.raw
+
+    @classmethod
+    def rccl(cls, ctx, comm_id, world, rank):
+        if len(comm_id) != COMM_ID_BYTES:
+            raise ValueError(f"the RCCL id has {COMM_ID_BYTES} bytes")
+        h = C.c_void_p()
+        _check(_lib.ntt_comm_create_rccl(ctx._h, C.c_char_p(bytes(comm_id)), int(world), int(rank), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def host(cls, ctx, alltoall, world, rank):
+        world = int(world)
+
+        def thunk(_user, send, recv, nbytes):
+            try:
+                shape = (world, int(nbytes))
+                s = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=shape)
+                r = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=shape)
+                alltoall(s, r)
+                return 0
+            except Exception:                # an exception must not unwind through the C frames above
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = ALLTOALL_FN(thunk)
+        h = C.c_void_p()
+        _check(_lib.ntt_comm_create_host(ctx._h, cb, None, world, int(rank), C.byref(h)))
+        return cls(ctx, h, keep=cb)
+
+    def close(self):
+        if self._h:
+            if self.ctx._h:
+                _lib.ntt_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def dist_forward(self, dplan, x_local, out):
+        """x_local = x[rank*S:(rank+1)*S] (device) -> out[k2] = X[rank + world*k2] (``ntt_comm_dist_forward``)."""
+        S = dplan.local_length
+        _check(_lib.ntt_comm_dist_forward(self._h, dplan._h, _ptr(x_local, np.uint32, S), _ptr(out, np.uint32, S)))
+        return out
+
+    def dist_inverse(self, dplan, X_local, out):
+        S = dplan.local_length
+        _check(_lib.ntt_comm_dist_inverse(self._h, dplan._h, _ptr(X_local, np.uint32, S), _ptr(out, np.uint32, S)))
+        return out
+
+    def crt_multiply(self, a, b, p64, out=None):
+        """Prime-per-rank large-modulus product; a, b (uint64 [n], the same on every rank) -> 2n-1 uint64 on every rank."""
+        n = int(a.shape[-1])
+        if out is None:
+            out = np.zeros(2 * n - 1, dtype=np.uint64)
+        _check(_lib.ntt_comm_crt_multiply(self._h, _ptr(a, np.uint64, n), _ptr(b, np.uint64, n),
+                                          _ptr(out, np.uint64, 2 * n - 1), n, int(p64)))
+        return out
 
 
 class _PinnedOwner:

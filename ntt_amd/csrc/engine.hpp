@@ -93,6 +93,10 @@ int group_transform(ntt_plan *pl, uint32_t *data, int batch, bool inverse);
 int group_crt_multiply(ntt_ctx *g, const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p64, int batch);
 int group_dist_plan_create(ntt_ctx *g, uint32_t p, int lgL, int world, int kind, ntt_dist_plan **out);
 void group_dist_plan_release(ntt_dist_plan *dp);
+// multidev.cpp: the pointer-table column kernel (kernels_dist.hip) on one rank's piece -- row i1 read at src[i1], row k1
+// written at dst[k1], columns [col0, col0 + ncols) of the S / world the rank owns; world <= kMaxDistWorld
+int dist_colpass_tables(ntt_dist_plan *part, bool inverse, bool half, const uint32_t *const *src, uint32_t *const *dst,
+                        uint32_t col0, uint32_t ncols, hipStream_t stream);
 
 }  // namespace ntt
 

@@ -31,6 +31,7 @@
 
 #include "../../include/ntt_amd.h"
 #include "engine.hpp"
+#include "rccl_dl.hpp"
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
@@ -46,18 +47,7 @@ namespace ntt {
 // and every default path here is plain HIP.  Only NTT_AMD_DIST_TRANSPORT=rccl opens it (dlopen, local symbols) and uses
 // the six calls below -- the grouped ncclSend / ncclRecv form of an all-to-all, one communicator per slot in this one
 // process (ncclCommInitAll), each pair of calls on the slot's own exchange stream.
-struct Rccl {
-    void *lib = nullptr;
-    int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
-    int (*CommDestroy)(void *comm) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    int (*Send)(const void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t stream) = nullptr;
-    int (*Recv)(void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t stream) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
-    static constexpr int kUint32 = 3;                    // ncclUint32 (rccl.h)
-};
-static Rccl *rccl_load()
+Rccl *rccl_load()
 {
     static std::mutex mu;
     static Rccl r;
@@ -78,7 +68,9 @@ static Rccl *rccl_load()
             r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
             r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
             r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-            if (!r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv || !r.GetErrorString) {
+            r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+            r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+            if (!r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv || !r.GetErrorString) {
                 dlclose(r.lib);
                 r.lib = nullptr;
             }
@@ -86,12 +78,6 @@ static Rccl *rccl_load()
     }
     return r.lib ? &r : nullptr;
 }
-#define RCCL_TRY(R, expr)                                                                                          \
-    do {                                                                                                           \
-        const int e_ = (expr);                                                                                     \
-        if (e_ != 0) return ntt::fail(NTT_ERR_HIP, std::string(#expr) + ": " + (R)->GetErrorString(e_));           \
-    } while (0)
-
 struct GroupCrt {
     int n = 0;
     size_t sl = 0;                                       // coefficients per slot slice
@@ -537,15 +523,15 @@ int group_dist_plan_create(ntt_ctx *g, uint32_t p, int lgL, int world, int kind,
     return NTT_OK;
 }
 
-// the column kernel of slot h over columns [col0, col0 + ncols) of its piece
+// the column kernel of one rank's piece (`part`: a single-device plan) over columns [col0, col0 + ncols): row i1 is read
+// at src[i1], row k1 is written at dst[k1] -- wherever those arrays live (the slot's own memory, a peer's, staging)
 template <class MM>
-static int launch_slot_colpass(ntt_dist_plan *dp, int h, bool inverse, bool half, const uint32_t *const *src, uint32_t *const *dst,
+static int launch_part_colpass(ntt_dist_plan *part, bool inverse, bool half, const uint32_t *const *src, uint32_t *const *dst,
                                uint32_t col0, uint32_t ncols, hipStream_t stream)
 {
-    ntt_dist_plan *part = dp->part[(size_t)h];
     ntt_plan *cp = part->colp;
-    const int G = dp->world;
-    const uint32_t cols = dp->S / (uint32_t)G;
+    const int G = part->world;
+    const uint32_t cols = part->S / (uint32_t)G;
     DistColArgs<MM> a{};
     for (int i = 0; i < G; ++i) {
         a.in[i] = src[i];
@@ -565,6 +551,14 @@ static int launch_slot_colpass(ntt_dist_plan *dp, int h, bool inverse, bool half
     return NTT_OK;
 }
 
+int dist_colpass_tables(ntt_dist_plan *part, bool inverse, bool half, const uint32_t *const *src, uint32_t *const *dst,
+                        uint32_t col0, uint32_t ncols, hipStream_t stream)
+{
+    if (part->world > kMaxDistWorld) return fail(NTT_ERR_UNSUPPORTED, "the pointer-table column kernel serves at most 16 ranks");
+    return part->colp->kind == NTT_MODMUL_MONTGOMERY ? launch_part_colpass<Mont32>(part, inverse, half, src, dst, col0, ncols, stream)
+                                                      : launch_part_colpass<Barrett32>(part, inverse, half, src, dst, col0, ncols, stream);
+}
+
 // Forward: in[r] = x[r * S .. (r + 1) * S) on slot r  ->  out[r][k2] = X[r + world * k2].
 // Inverse: the reverse, scaled by L^-1.  Everything is queued; ntt_ctx_synchronize(group) waits for it.
 // scrambled: the local transforms leave / take the spectrum in the engine's own order (no permutation pass): the two
@@ -578,7 +572,6 @@ static int group_dist_run(ntt_dist_plan *dp, const uint32_t *const *in, uint32_t
     const uint32_t S = dp->S, cols = S / (uint32_t)G;
     const int C = dp->chunks;
     const uint32_t cc = cols / (uint32_t)C;
-    const int kind = dp->part[0]->colp->kind;
     const int nz = (half && !inverse) ? G / 2 : G;            // rows (= blocks) that hold data
     // every slot starts behind the end of the previous call on EVERY slot: peers are about to write into its arrays
     for (int s = 0; s < G; ++s) {
@@ -650,8 +643,7 @@ static int group_dist_run(ntt_dist_plan *dp, const uint32_t *const *in, uint32_t
                 HIP_TRY(hipEventRecord(gs.ev_in[(size_t)ch], gs.copy_in));
                 HIP_TRY(hipStreamWaitEvent(sh, gs.ev_in[(size_t)ch], 0));
             }
-            const int rc = kind == NTT_MODMUL_MONTGOMERY ? launch_slot_colpass<Mont32>(dp, h, inverse, half, src, dst, c0, cc, sh)
-                                                         : launch_slot_colpass<Barrett32>(dp, h, inverse, half, src, dst, c0, cc, sh);
+            const int rc = dist_colpass_tables(dp->part[(size_t)h], inverse, half, src, dst, c0, cc, sh);
             if (rc) return rc;
             if (dp->transport >= 2) {                       // exchange out: row k1 of this chunk to slot k1
                 HIP_TRY(hipEventRecord(gs.ev_k[(size_t)ch], sh));

@@ -121,6 +121,9 @@ def test_bench_gpus_flag_on_one_gpu(world):
     assert also.get("mdev_checks") == "ok", also
     assert also["mdev_devices"] == ",".join(["0"] * world) and also["mdev_crt4_n2p17_ms"] > 0
     assert also["mdev_ntt2p26_p2p_fwd_inv_ms"] > 0 and also["mdev_ntt2p26_copy_fwd_inv_ms"] > 0
+    # ... and the process-per-GPU communicator (ntt_comm), run as a child job of `world` ranks (host mode here: gloo)
+    assert also.get("comm_checks") == "ok" and also["comm_kind"] == "host" and also["comm_world"] == world, also
+    assert also["comm_crt4_n2p17_ms"] > 0 and also["comm_ntt2p26_fwd_inv_ms"] > 0
     assert also["mdev_batch_products_per_s"] > 0 and also["mdev_batch_per_slot"] == 512      # arrays per slot, one process
 
 

@@ -49,7 +49,8 @@ KERNELS = {
 def source_stamp():
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)):
-        if f.endswith((".hip", ".hpp")):            # the device code: kernels and the headers they include
+        # the device code: kernels and the headers they include (engine.hpp, rccl_dl.hpp are host-only: no kernel sees them)
+        if f.endswith((".hip", ".hpp")) and f not in ("engine.hpp", "rccl_dl.hpp"):
             h.update(f.encode())
             h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:16]
