@@ -319,6 +319,10 @@ int ntt_comm_destroy(ntt_comm *comm);
 int ntt_comm_size(const ntt_comm *comm, int *world, int *rank, int *kind /* 0 host, 1 rccl */);
 int ntt_comm_dist_forward(ntt_comm *comm, ntt_dist_plan *plan, const uint32_t *in, uint32_t *out);
 int ntt_comm_dist_inverse(ntt_comm *comm, ntt_dist_plan *plan, const uint32_t *in, uint32_t *out);
+/* ntt_dist_multiply for one process per GPU: rank r < world / 2 passes block r (S words, device) of a and of b -- the
+ * other ranks' a, b are not read (NULL allowed) -- and every rank receives block `rank` of the L - 1 product
+ * coefficients in ab (device, S words).  No reordering pass; queued like ntt_comm_dist_forward. */
+int ntt_comm_dist_multiply(ntt_comm *comm, ntt_dist_plan *plan, const uint32_t *a, const uint32_t *b, uint32_t *ab);
 int ntt_comm_crt_multiply(ntt_comm *comm, const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p64);
 
 /* Per-kernel timing (HIP events on the context's stream) for bench.py's roofline block.

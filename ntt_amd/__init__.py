@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = (
     "ntt_crt_residue_multiply", "ntt_crt_merge", "ntt_dist_plan_create", "ntt_dist_plan_destroy",
     "ntt_dist_colpass", "ntt_dist_local", "ntt_dist_local_length",
     "ntt_ctx_device_count", "ntt_ctx_device", "ntt_partition", "ntt_poly_multiply_batched_slots", "ntt_dist_forward", "ntt_dist_inverse", "ntt_dist_plan_transport", "ntt_dist_multiply",
-    "ntt_comm_rccl_id", "ntt_comm_create_rccl", "ntt_comm_create_host", "ntt_comm_destroy", "ntt_comm_size", "ntt_comm_dist_forward", "ntt_comm_dist_inverse", "ntt_comm_crt_multiply",
+    "ntt_comm_rccl_id", "ntt_comm_create_rccl", "ntt_comm_create_host", "ntt_comm_destroy", "ntt_comm_size", "ntt_comm_dist_forward", "ntt_comm_dist_inverse", "ntt_comm_dist_multiply", "ntt_comm_crt_multiply",
     "ntt_ctx_enable_kernel_timing", "ntt_ctx_kernel_timing_select", "ntt_ctx_kernel_timing_stride", "ntt_ctx_kernel_time", "ntt_last_error", "ntt_read_case",
     "ntt_check_case", "ntt_write_case", "ntt_poly_multiply_stream", "ntt_host_alloc", "ntt_host_free",
     "ntt_pack_case", "ntt_read_case_bin", "ntt_check_case_bin", "ntt_write_case_bin",
@@ -118,6 +118,7 @@ def _load():
     lib.ntt_comm_dist_forward.argtypes = [vp, vp, vp, vp]
     lib.ntt_comm_dist_inverse.argtypes = [vp, vp, vp, vp]
     lib.ntt_comm_crt_multiply.argtypes = [vp, vp, vp, vp, i32, u64]
+    lib.ntt_comm_dist_multiply.argtypes = [vp, vp, vp, vp, vp]
     lib.ntt_ctx_enable_kernel_timing.argtypes = [vp, i32]
     lib.ntt_ctx_kernel_timing_select.argtypes = [vp, i32]
     lib.ntt_ctx_kernel_timing_stride.argtypes = [vp, i32]
@@ -609,6 +610,14 @@ class Comm:
         S = dplan.local_length
         _check(_lib.ntt_comm_dist_inverse(self._h, dplan._h, _ptr(X_local, np.uint32, S), _ptr(out, np.uint32, S)))
         return out
+
+    def dist_multiply(self, dplan, a_block, b_block, ab_block):
+        """The product of two polynomials of L/2 coefficients: ranks below world/2 pass their block of a and of b (the
+        others None), every rank receives its block of the L-1 product coefficients (``ntt_comm_dist_multiply``)."""
+        S = dplan.local_length
+        opt = lambda x: _ptr(x, np.uint32, S) if x is not None else None
+        _check(_lib.ntt_comm_dist_multiply(self._h, dplan._h, opt(a_block), opt(b_block), _ptr(ab_block, np.uint32, S)))
+        return ab_block
 
     def crt_multiply(self, a, b, p64, out=None):
         """Prime-per-rank large-modulus product; a, b (uint64 [n], the same on every rank) -> 2n-1 uint64 on every rank."""

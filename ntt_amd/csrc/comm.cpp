@@ -37,6 +37,7 @@ struct ntt_comm {
     hipEvent_t start = nullptr, out_done = nullptr;
     std::vector<hipEvent_t> ev_in, ev_k;                   // per column chunk
     ntt::DeviceBuffer row, held, sent;                     // split transform: [S] each
+    ntt::DeviceBuffer spec_a, spec_b;                      // split product: the two spectra of this rank
     void *host_send = nullptr, *host_recv = nullptr;       // pinned staging (host mode)
     size_t host_bytes = 0;
     int crt_n = 0;                                         // large-modulus product: buffers sized for this n
@@ -71,36 +72,44 @@ static int call_alltoall(ntt_comm *cm, size_t bytes_per_rank)
 // recv[i][c0 .. c0 + cc) <- columns [c0, c0 + cc) of block `rank` of rank i's `send`, for two [world][cols] u32 arrays:
 // the all-to-all of the distributed 4-step (include/ntt_amd.h, ntt_dist_*).  RCCL: queued on `stream`.  Host mode:
 // through the pinned buffers and the callback, synchronously; the copy back to the device is queued on `stream`.
-static int exchange_blocks(ntt_comm *cm, const uint32_t *send, uint32_t *recv, size_t cols, size_t c0, size_t cc, hipStream_t stream)
+// nz < world: only ranks below nz hold data (the zero-padded half of a product's forward transform) -- the others send
+// nothing, and nothing is received from them (their rows of recv are left as they are: the HALF kernel does not read them).
+static int exchange_blocks(ntt_comm *cm, const uint32_t *send, uint32_t *recv, size_t cols, size_t c0, size_t cc, hipStream_t stream, int nz)
 {
     const int W = cm->world;
+    const bool sender = cm->rank < nz;
     if (cm->rccl) {
         Rccl *r = rccl_load();
         if (!r) return fail(NTT_ERR_INTERNAL, "ntt_comm: librccl went away");
         RCCL_TRY(r, r->GroupStart());
         for (int i = 0; i < W; ++i) {
-            RCCL_TRY(r, r->Send(send + (size_t)i * cols + c0, cc, Rccl::kUint32, i, cm->nccl, stream));
-            RCCL_TRY(r, r->Recv(recv + (size_t)i * cols + c0, cc, Rccl::kUint32, i, cm->nccl, stream));
+            if (sender) RCCL_TRY(r, r->Send(send + (size_t)i * cols + c0, cc, Rccl::kUint32, i, cm->nccl, stream));
+            if (i < nz) RCCL_TRY(r, r->Recv(recv + (size_t)i * cols + c0, cc, Rccl::kUint32, i, cm->nccl, stream));
         }
         RCCL_TRY(r, r->GroupEnd());
         return NTT_OK;
     }
     const size_t bytes = cc * sizeof(uint32_t);
     if (int rc = ensure_host(cm, bytes * (size_t)W)) return rc;
-    HIP_TRY(hipMemcpy2DAsync(cm->host_send, bytes, send + c0, cols * sizeof(uint32_t), bytes, (size_t)W, hipMemcpyDeviceToHost, stream));
+    if (sender) HIP_TRY(hipMemcpy2DAsync(cm->host_send, bytes, send + c0, cols * sizeof(uint32_t), bytes, (size_t)W, hipMemcpyDeviceToHost, stream));
+    else std::memset(cm->host_send, 0, bytes * (size_t)W);   // the host program's all-to-all moves every block
     HIP_TRY(hipStreamSynchronize(stream));
     if (int rc = call_alltoall(cm, bytes)) return rc;
-    HIP_TRY(hipMemcpy2DAsync(recv + c0, cols * sizeof(uint32_t), cm->host_recv, bytes, bytes, (size_t)W, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpy2DAsync(recv + c0, cols * sizeof(uint32_t), cm->host_recv, bytes, bytes, (size_t)nz, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));                   // host_recv is free again for the next exchange
     return NTT_OK;
 }
 
-static int comm_dist_run(ntt_comm *cm, ntt_dist_plan *dp, const uint32_t *in, uint32_t *out, bool inverse)
+// scrambled: the local transforms leave / take the spectrum in the engine's own order; half (forward only): the blocks of
+// ranks >= world / 2 are zero padding (`in` is not read there) -- the two halves of ntt_comm_dist_multiply
+static int comm_dist_run(ntt_comm *cm, ntt_dist_plan *dp, const uint32_t *in, uint32_t *out, bool inverse, bool scrambled = false,
+                         bool half = false)
 {
     ntt_ctx *cx = cm->ctx;
     const int W = cm->world;
     const uint32_t S = dp->S, cols = S / (uint32_t)W;
     const size_t bytes = (size_t)S * sizeof(uint32_t);
+    const int nz = (half && !inverse) ? W / 2 : W;          // ranks whose block holds data
     HIP_TRY(hipSetDevice(cx->device));
     int rc = cm->held.ensure(bytes);
     if (!rc) rc = cm->sent.ensure(bytes);
@@ -111,7 +120,7 @@ static int comm_dist_run(ntt_comm *cm, ntt_dist_plan *dp, const uint32_t *in, ui
     const uint32_t *first = in;
     if (inverse) {                                           // local S-point inverse transforms first: in -> row
         uint32_t *rowp = static_cast<uint32_t *>(cm->row.ptr);
-        if ((rc = transform_device_any(dp->local, in, rowp, true))) return rc;
+        if ((rc = transform_device_any(dp->local, in, rowp, true, scrambled))) return rc;
         first = rowp;
     }
     const uint32_t *src[kMaxDistWorld];
@@ -124,33 +133,33 @@ static int comm_dist_run(ntt_comm *cm, ntt_dist_plan *dp, const uint32_t *in, ui
     while (C > 1 && (cols % ((uint32_t)C * 256u)) != 0) --C;
     const uint32_t cc = cols / (uint32_t)C;
     if (!cm->rccl) {
-        if ((rc = exchange_blocks(cm, first, held, cols, 0, cols, cs))) return rc;
-        if ((rc = dist_colpass_tables(dp, inverse, false, src, dst, 0, cols, cs))) return rc;
-        if ((rc = exchange_blocks(cm, sent, out, cols, 0, cols, cs))) return rc;
+        if ((rc = exchange_blocks(cm, first, held, cols, 0, cols, cs, nz))) return rc;
+        if ((rc = dist_colpass_tables(dp, inverse, half, src, dst, 0, cols, cs))) return rc;
+        if ((rc = exchange_blocks(cm, sent, out, cols, 0, cols, cs, W))) return rc;
     } else {
         // exchange stream xs beside compute stream cs: in(0) | in(1), colpass(0) | out(0), in(2), colpass(1) | ...
         hipStream_t xs = cm->xs;
         HIP_TRY(hipEventRecord(cm->start, cs));
         HIP_TRY(hipStreamWaitEvent(xs, cm->start, 0));
-        if ((rc = exchange_blocks(cm, first, held, cols, 0, cc, xs))) return rc;
+        if ((rc = exchange_blocks(cm, first, held, cols, 0, cc, xs, nz))) return rc;
         HIP_TRY(hipEventRecord(cm->ev_in[0], xs));
         for (int ch = 0; ch < C; ++ch) {
             const uint32_t c0 = (uint32_t)ch * cc;
             if (ch + 1 < C) {
-                if ((rc = exchange_blocks(cm, first, held, cols, c0 + cc, cc, xs))) return rc;
+                if ((rc = exchange_blocks(cm, first, held, cols, c0 + cc, cc, xs, nz))) return rc;
                 HIP_TRY(hipEventRecord(cm->ev_in[(size_t)ch + 1], xs));
             }
             HIP_TRY(hipStreamWaitEvent(cs, cm->ev_in[(size_t)ch], 0));
-            if ((rc = dist_colpass_tables(dp, inverse, false, src, dst, c0, cc, cs))) return rc;
+            if ((rc = dist_colpass_tables(dp, inverse, half, src, dst, c0, cc, cs))) return rc;
             HIP_TRY(hipEventRecord(cm->ev_k[(size_t)ch], cs));
             HIP_TRY(hipStreamWaitEvent(xs, cm->ev_k[(size_t)ch], 0));
-            if ((rc = exchange_blocks(cm, sent, out, cols, c0, cc, xs))) return rc;
+            if ((rc = exchange_blocks(cm, sent, out, cols, c0, cc, xs, W))) return rc;
         }
         HIP_TRY(hipEventRecord(cm->out_done, xs));
         HIP_TRY(hipStreamWaitEvent(cs, cm->out_done, 0));
     }
     HIP_TRY(hipGetLastError());
-    if (!inverse) return transform_device_any(dp->local, out, out, false);
+    if (!inverse) return transform_device_any(dp->local, out, out, false, scrambled);
     return NTT_OK;
 }
 
@@ -268,6 +277,7 @@ static void comm_release(ntt_comm *cm)
     if (cm->nccl)
         if (Rccl *r = rccl_load()) (void)r->CommDestroy(cm->nccl);
     cm->row.release(); cm->held.release(); cm->sent.release();
+    cm->spec_a.release(); cm->spec_b.release();
     cm->crt_send.release(); cm->crt_recv.release(); cm->crt_mine.release(); cm->crt_full.release();
     if (cm->host_send) (void)hipHostFree(cm->host_send);
     if (cm->host_recv) (void)hipHostFree(cm->host_recv);
@@ -384,6 +394,35 @@ NTT_CATCH_STATUS
 int ntt_comm_dist_inverse(ntt_comm *comm, ntt_dist_plan *plan, const uint32_t *in, uint32_t *out)
 try {
     return comm_dist_entry(comm, plan, in, out, true, "ntt_comm_dist_inverse");
+}
+NTT_CATCH_STATUS
+
+int ntt_comm_dist_multiply(ntt_comm *cm, ntt_dist_plan *dp, const uint32_t *a, const uint32_t *b, uint32_t *ab)
+try {
+    const char *who = "ntt_comm_dist_multiply";
+    if (!cm || !dp || !ab) return fail(NTT_ERR_INVALID, std::string(who) + ": null argument");
+    if (!dp->part.empty() || dp->ctx != cm->ctx)
+        return fail(NTT_ERR_INVALID, std::string(who) + ": the plan must come from ntt_dist_plan_create on the communicator's own single-device context");
+    if (dp->world != cm->world || dp->rank != cm->rank) return fail(NTT_ERR_INVALID, std::string(who) + ": the plan's world / rank differ from the communicator's");
+    if (dp->world > kMaxDistWorld) return fail(NTT_ERR_UNSUPPORTED, std::string(who) + ": at most 16 ranks");
+    const bool holds = cm->rank < cm->world / 2;             // the upper half of both operands is the zero padding
+    if (holds && (!a || !b)) return fail(NTT_ERR_INVALID, std::string(who) + ": ranks below world / 2 pass their block of a and of b");
+    if ((holds && (!is_device_ptr(a) || !is_device_ptr(b))) || !is_device_ptr(ab))
+        return fail(NTT_ERR_INVALID, std::string(who) + ": blocks must be device arrays of S = L / world words");
+    std::lock_guard<std::mutex> lk(cm->mu);
+    HIP_TRY(hipSetDevice(cm->ctx->device));
+    const size_t bytes = (size_t)dp->S * sizeof(uint32_t);
+    int rc = cm->spec_a.ensure(bytes);
+    if (!rc) rc = cm->spec_b.ensure(bytes);
+    if (rc) return rc;
+    uint32_t *spa = static_cast<uint32_t *>(cm->spec_a.ptr), *spb = static_cast<uint32_t *>(cm->spec_b.ptr);
+    if ((rc = comm_dist_run(cm, dp, holds ? a : nullptr, spa, false, true, true))) return rc;
+    if ((rc = comm_dist_run(cm, dp, holds ? b : nullptr, spb, false, true, true))) return rc;
+    ntt_plan *lp = dp->local;
+    HIP_TRY(hipSetDevice(cm->ctx->device));
+    launch_dist_pointwise(lp->kind, lp->lazy, spa, spb, dp->S, lp->mp, cm->ctx->stream);     // behind the local transforms (stream order)
+    HIP_TRY(hipGetLastError());
+    return comm_dist_run(cm, dp, spa, ab, true, true);
 }
 NTT_CATCH_STATUS
 

@@ -85,6 +85,21 @@ def main():
             comm.dist_inverse(dp, fwd, back)
             ctx.synchronize()
             check(np.array_equal(back.cpu().numpy().view(np.uint32), x[rank * S:(rank + 1) * S]), f"inverse p={p} lgL={lgL}")
+        # the split product: two polynomials of L / 2 coefficients, blocks on the lower half of the ranks
+        half = L // 2
+        pa = (orc.splitmix64_np(5 + lgL, half) % np.uint64(p)).astype(np.uint32)
+        pb = (orc.splitmix64_np(6 + lgL, half) % np.uint64(p)).astype(np.uint32)
+        pa[:3] = p - 1
+        pb[-3:] = p - 1
+        want = np.concatenate([orc.poly_multiply(pa, pb, p), np.zeros(1, dtype=np.uint32)])
+        blk = lambda v: torch.from_numpy(v[rank * S:(rank + 1) * S].view(np.int32).copy()).cuda() if rank < G // 2 else None
+        da, db = blk(pa), blk(pb)
+        dab = torch.full((S,), -1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(2):
+            comm.dist_multiply(dp, da, db, dab)
+            ctx.synchronize()
+            check(np.array_equal(dab.cpu().numpy().view(np.uint32), want[rank * S:(rank + 1) * S]), f"split product p={p} lgL={lgL}")
         # argument checks: host arrays, in == out, a plan of another rank
         for bad in (lambda: comm.dist_forward(dp, mine, mine), lambda: comm.dist_forward(dp, mine.cpu().numpy().view(np.uint32), fwd)):
             try:
