@@ -312,3 +312,60 @@ def test_pinned_host_arrays_are_used_in_place(nt, ctx):
     iab = nt.host_array(2 * n - 1, np.int32)
     nt._lib.poly_multiply(ia.ctypes.data, ib.ctypes.data, iab.ctypes.data, n, p)
     assert np.array_equal(iab.view(np.uint32), orc.poly_multiply(ia.view(np.uint32), ib.view(np.uint32), p))
+
+
+def test_object_lifetimes_return_their_device_memory(nt):
+    """Every kind of object the library hands out, created, used and closed in a loop: the device's free memory comes back
+    to where it was after the first (warm-up) cycle -- plans with their work buffers and tables, the CRT workspaces of a
+    context and of a multi-device context, streamed-product rings, 64-bit plans, split-transform plans with their
+    exchange buffers and streams, a communicator with its staging."""
+    import torch
+    p, p64 = 998244353, 1337006139375617
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, p, size=(6, 20000), dtype=np.int64).astype(np.uint32)
+    b = rng.integers(0, p, size=(6, 20000), dtype=np.int64).astype(np.uint32)
+    a64 = rng.integers(0, p64, size=(3, 9000), dtype=np.uint64)
+    b64 = rng.integers(0, p64, size=(3, 9000), dtype=np.uint64)
+    first = {}
+
+    def cycle(tag):
+        ctx = nt.Context(0)
+        pl = ctx.plan(p, 20000, 6)
+        r1 = pl.multiply(a, b)
+        r2 = pl.multiply_stream(a, b)
+        ng = ctx.negacyclic_plan(p, 16384, 2).multiply(a[:2, :16384].copy(), b[:2, :16384].copy())
+        c1 = ctx.crt_multiply_batched(a64, b64, p64)
+        p6 = ctx.plan64(p64, 9000, 3)
+        c2 = p6.multiply(a64, b64)
+        dp = nt.DistPlan(ctx, 469762049, 16, 4, 1)
+        d = torch.zeros(dp.local_length, dtype=torch.int32, device="cuda")
+        dp.colpass(d)
+        comm = nt.Comm.host(ctx, lambda s, r: r.__setitem__(Ellipsis, s), 1, 0)
+        c3 = comm.crt_multiply(a64[0], b64[0], p64)
+        ctx.synchronize()
+        del d
+        ctx.close()                                                          # closes pl, p6, dp, comm with it
+        grp = nt.Context(devices=[0, 0])
+        gp = grp.plan(p, 20000, 6)
+        r3 = gp.multiply(a, b)
+        c4 = grp.crt_multiply(a64[0], b64[0], p64)
+        gd = nt.DistPlan(grp, 469762049, 16, 2, 0)
+        xs = [torch.zeros(gd.local_length, dtype=torch.int32, device="cuda") for _ in range(4)]
+        gd.forward(xs[:2], xs[2:])
+        grp.synchronize()
+        del xs
+        grp.close()
+        got = (r1, r2, ng, c1, c2, c3, r3, c4)
+        if not first:
+            first[0] = got
+        else:
+            assert all(np.array_equal(x, y) for x, y in zip(got, first[0])), tag
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        return torch.cuda.mem_get_info()[0]
+
+    assert np.array_equal(cycle("warm-up") and first[0][0][2], orc.poly_multiply(a[2], b[2], p))
+    base = cycle("base")
+    for i in range(6):
+        free = cycle(i)
+    assert free >= base - (4 << 20), f"{(base - free) >> 20} MiB of device memory did not come back over 6 cycles"
