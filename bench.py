@@ -228,7 +228,7 @@ def _eval_point_t(torch, x, wk, p, blk=1 << 13):
     return int(((sums * pws) % p).sum() % p)
 
 
-def also_block(args, group, rank, world, local_rank):
+def also_block(args, group, rank, world, local_rank, out=None):
     """The sharded workloads of SURVEY 8(e) beside the headline one (flat dict of scalars): (a) BASELINE.json
     configs[2], the 4-prime CRT product at n = 2^17 with the primes partitioned over the ranks and the slice exchange
     (main-mpi.cc:657-660, 739-797) through shard.CrtExchange; (b) configs[3], 32 RNS limbs x 256 pairs at n = 2^16, limbs
@@ -240,7 +240,7 @@ def also_block(args, group, rank, world, local_rank):
     import ntt_amd
     import orc
     from ntt_amd import shard
-    out, failed = {}, []
+    out, failed = ({} if out is None else out), []         # `out` fills as the entries finish (the caller's watchdog reads it)
     on_device = args.backend == "nccl" or group.dist is None
     ctx = ntt_amd.Context(local_rank)
 
@@ -669,32 +669,7 @@ def main(argv=None):
         plan1.close()
         ctx1.close()
 
-    # the other sharded workloads, behind the headline loop; a watchdog keeps a hung exchange from taking the line along
-    also = None
-    if not args.no_also and not args.no_kernel_timing:
-        import threading
-        headline = {"value": world * B * args.steps / elapsed, "n_gpus": world, "ms_per_step": 1e3 * elapsed / args.steps}
-
-        def give_up():
-            if rank == 0:
-                print(json.dumps({"metric": "poly-mults/sec at n=2^17 (32-bit p)", "unit": "poly-mults/s", "steps": args.steps,
-                                  "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                                  "dtype": "u32", "data": "synthetic", **headline,
-                                  "also": {"error": f"the also block did not finish within {args.also_timeout} s; headline only"}}),
-                      flush=True)
-            os._exit(0)
-        dog = threading.Timer(args.also_timeout, give_up)
-        dog.daemon = True
-        dog.start()
-        try:
-            also = also_block(args, group, rank, world, local_rank)
-        except Exception as e:                       # the headline measurement stands; say what happened
-            also = {"error": f"{type(e).__name__}: {e}"[:300]}
-        dog.cancel()
-
-    rc = 0
-    if also is not None and (str(also.get("checks", "ok")) != "ok"):
-        rc = 1
+    line = None
     if rank == 0 and args.no_kernel_timing:         # sweeps (tools/): the rate only
         print(json.dumps({"value": world * B * args.steps / elapsed, "n_gpus": world,
                           "ms_per_step": 1e3 * elapsed / args.steps, "chunk": args.chunk}), flush=True)
@@ -790,11 +765,38 @@ def main(argv=None):
                          "kernel_ms_per_step_untimed": {k: v[0] / 2 for k, v in warm_ktimes.items()},
                          "kernels_one_lane": one_lane, "valu": valu, "sustained": sustained},
         }
+        line = out
+
+    # the other sharded workloads, behind the headline loop and after the headline line is complete: a watchdog keeps a
+    # hung exchange from taking the line along -- it prints the line with whatever part of the block had finished
+    also = None
+    if not args.no_also and not args.no_kernel_timing:
+        import threading
+        partial = {}
+
+        def give_up():
+            if rank == 0:
+                line["also"] = dict(partial, error=f"the also block did not finish within {args.also_timeout} s; entries so far")
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        dog = threading.Timer(args.also_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            also = also_block(args, group, rank, world, local_rank, partial)
+        except Exception as e:                       # the headline measurement stands; say what happened
+            also = dict(partial, error=f"{type(e).__name__}: {e}"[:300])
+        dog.cancel()
+
+    rc = 0
+    if also is not None and (str(also.get("checks", "ok")) != "ok"):
+        rc = 1
+    if line is not None:
         if also is not None:
-            out["also"] = also
+            line["also"] = also
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, p, args.cpu_seconds, gpu_row0, args.with_ref)
-        print(json.dumps(out), flush=True)
+            line["cpu_baseline"] = cpu_baseline(n, p, args.cpu_seconds, gpu_row0, args.with_ref)
+        print(json.dumps(line), flush=True)
 
     barrier()                       # rank 0 ran the one-lane table meanwhile: every rank leaves the group together
     plan.close()

@@ -141,3 +141,20 @@ def test_bench_also_block_one_rank():
     also = j["also"]
     assert also["checks"] == "ok" and also["ntt2p26_sent_bytes_per_rank"] == 0 and also["crt4_sent_bytes_per_rank"] == 0, also
     assert also["rns_products_per_s"] > 1e5 and also["crt4_n2p17_ms"] < 5 and also["ntt2p26_fwd_inv_ms"] < 50
+
+
+def test_bench_watchdog_keeps_the_headline_line():
+    """A hung `also` block must not cost the line: with a watchdog far too short for the block, bench.py still prints
+    the complete headline line (roofline included) with the entries that had finished and the reason."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--batch", "96", "--sustained-seconds", "0", "--no-one-lane", "--also-timeout", "0.05"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["value"] > 0 and j["n_gpus"] == 1 and j["roofline"]["frac"] > 0 and j["config"]["batch_per_gpu"] == 96
+    assert "did not finish" in j["also"]["error"] and "checks" not in j["also"]
