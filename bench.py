@@ -295,12 +295,13 @@ def also_block(args, group, rank, world, local_rank, out=None):
     gen.manual_seed(4 + rank)
     ra = torch.randint(0, 1 << 30, (polys, n), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32)
     rb = torch.randint(0, 1 << 30, (polys, n), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32)
-    rab = torch.empty((polys, 2 * n - 1), dtype=torch.int32, device="cuda")
+    rab_all = torch.empty((max(count, 1), polys, 2 * n - 1), dtype=torch.int32, device="cuda")    # the limbs run side by side
+    rab = rab_all[max(count, 1) - 1]
     plans = [ctx.plan(primes[start + j], n, polys) for j in range(count)]
 
-    def rns():
-        for pl in plans:
-            pl.multiply(ra, rb, out=rab, batch=polys)
+    def rns():                                            # every limb of this rank in ONE call (ntt_poly_multiply_limbs)
+        if plans:
+            ntt_amd.multiply_limbs(plans, [ra] * count, [rb] * count, [rab_all[j] for j in range(count)], polys)
     if plans:
         rns()
         sync()
@@ -327,7 +328,7 @@ def also_block(args, group, rank, world, local_rank, out=None):
     out["rns_limbs_per_rank"] = -(-limbs // world)
     for pl in plans:
         pl.close()
-    del ra, rb, rab
+    del ra, rb, rab, rab_all
 
     # (c) one transform of 2^26 points, forward + inverse
     lgL, p = 26, 469762049

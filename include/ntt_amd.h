@@ -83,6 +83,17 @@ void poly_multiply(int *a, int *b, int *ab, int n, int p);
  *     slot: ntt_ctx_device(ctx, slot, &slot_ctx, &device) hands out the slot's single-device context, owned by ctx. */
 int ntt_ctx_create(const int *device_ids, int ndev, ntt_ctx **out_ctx);
 int ntt_ctx_device_count(const ntt_ctx *ctx);
+/* Products under SEVERAL moduli in one call -- RNS limbs (BASELINE.json configs[3]; the reference's four CRT primes are
+ * the same shape, main-openmp.cc:697: one thread per prime): limb i multiplies the `batch` rows of a[i], b[i] into ab[i]
+ * (row stride ab_stride) with plans[i] -- plans of ntt_plan_create (rows of 2n - 1 coefficients) or of
+ * ntt_negacyclic_plan_create (rows of n: the limbs of an x^n + 1 ring).  Distinct plans of ONE single-device context, device arrays only.  Each limb's
+ * chain of kernels runs whole on stream lane i % lanes through its plan's own work buffers, with one fork in front of
+ * the first limb and one join behind the last; a loop of ntt_poly_multiply_batched calls forks and joins the lanes per
+ * call instead, which drains the chip 32 times for 32 limbs (943 k vs 1 037 k products/s for 32 x 256 products at
+ * n = 2^16, profiles/rns_probe_r03.txt).  Queued; outputs of different limbs must not overlap (they are written
+ * concurrently). */
+int ntt_poly_multiply_limbs(ntt_plan *const *plans, int nlimbs, const uint32_t *const *a, const uint32_t *const *b,
+                            uint32_t *const *ab, size_t ab_stride, int batch);
 /* Products whose operands already live where they are multiplied: a plan of a multi-device context, one array triple per
  * slot -- a[s], b[s] are [count[s]][n], ab[s] is [count[s]][ab_stride], on (or reachable from) the device of slot s;
  * count[s] <= ceil(batch / slots), 0 for a slot without work.  The batch-per-GPU layout of BASELINE.json configs[1] /

@@ -43,7 +43,7 @@ EXPORTED_SYMBOLS = (
     "ntt_plan64_create", "ntt_plan64_destroy", "ntt_plan64_length", "ntt_poly_multiply64_batched",
     "ntt_crt_residue_multiply", "ntt_crt_merge", "ntt_dist_plan_create", "ntt_dist_plan_destroy",
     "ntt_dist_colpass", "ntt_dist_local", "ntt_dist_local_length",
-    "ntt_ctx_device_count", "ntt_ctx_device", "ntt_partition", "ntt_poly_multiply_batched_slots", "ntt_dist_forward", "ntt_dist_inverse", "ntt_dist_plan_transport", "ntt_dist_multiply",
+    "ntt_ctx_device_count", "ntt_ctx_device", "ntt_partition", "ntt_poly_multiply_batched_slots", "ntt_poly_multiply_limbs", "ntt_dist_forward", "ntt_dist_inverse", "ntt_dist_plan_transport", "ntt_dist_multiply",
     "ntt_comm_rccl_id", "ntt_comm_create_rccl", "ntt_comm_create_host", "ntt_comm_destroy", "ntt_comm_size", "ntt_comm_dist_forward", "ntt_comm_dist_inverse", "ntt_comm_dist_multiply", "ntt_comm_crt_multiply",
     "ntt_ctx_enable_kernel_timing", "ntt_ctx_kernel_timing_select", "ntt_ctx_kernel_timing_stride", "ntt_ctx_kernel_time", "ntt_last_error", "ntt_read_case",
     "ntt_check_case", "ntt_write_case", "ntt_poly_multiply_stream", "ntt_host_alloc", "ntt_host_free",
@@ -104,6 +104,7 @@ def _load():
     lib.ntt_dist_local_length.argtypes = [vp]
     lib.ntt_ctx_device_count.argtypes = [vp]
     lib.ntt_partition.argtypes = [C.c_long, i32, i32, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    lib.ntt_poly_multiply_limbs.argtypes = [C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), sz, i32]
     lib.ntt_poly_multiply_batched_slots.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), sz, C.POINTER(i32)]
     lib.ntt_ctx_device.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32)]
     lib.ntt_dist_forward.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
@@ -683,6 +684,23 @@ def write_case_bin(directory, case_id, ab, p):
     assert ab.dtype in (np.uint32, np.uint64)
     n = (ab.size + 1) // 2
     _check(_lib.ntt_write_case_bin(str(directory).encode(), case_id, ab.ctypes.data, n, int(p), ab.dtype.itemsize))
+
+
+def multiply_limbs(plans, a_list, b_list, out_list, batch, out_stride=None):
+    """Products under several moduli in one call (``ntt_poly_multiply_limbs``): limb i multiplies `batch` rows of
+    a_list[i], b_list[i] into out_list[i] with plans[i] -- distinct plans of one context, device arrays; queued."""
+    k = len(plans)
+    if not (len(a_list) == len(b_list) == len(out_list) == k):
+        raise ValueError("one array triple per plan")
+    n = plans[0].n
+    row = n if isinstance(plans[0], NegacyclicPlan) else 2 * n - 1
+    if out_stride is None:
+        out_stride = row
+    arr = lambda xs, need: (C.c_void_p * k)(*[_ptr(x, np.uint32, need).value for x in xs])
+    ph = (C.c_void_p * k)(*[pl._h.value for pl in plans])
+    _check(_lib.ntt_poly_multiply_limbs(ph, k, arr(a_list, batch * n), arr(b_list, batch * n),
+                                        arr(out_list, (batch - 1) * out_stride + row), out_stride, int(batch)))
+    return out_list
 
 
 def partition(total_units, world, rank):

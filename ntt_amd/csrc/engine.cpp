@@ -1176,6 +1176,77 @@ static int multiply_entry(ntt_plan *pl, const uint32_t *a, const uint32_t *b, ui
     return NTT_OK;
 }
 
+// Products under several moduli in one call (include/ntt_amd.h): limb i whole on stream lane i % lanes, through plan i's own
+// work buffers -- one fork before the first limb and one join behind the last instead of a fork / join per limb.
+int ntt_poly_multiply_limbs(ntt_plan *const *plans, int nlimbs, const uint32_t *const *a, const uint32_t *const *b,
+                            uint32_t *const *ab, size_t ab_stride, int batch)
+try {
+    const char *who = "ntt_poly_multiply_limbs";
+    if (!plans || !a || !b || !ab || nlimbs <= 0) return fail(NTT_ERR_INVALID, std::string(who) + ": null argument or no limbs");
+    if (batch <= 0) return fail(NTT_ERR_INVALID, std::string(who) + ": batch must be positive");
+    ntt_ctx *cx = plans[0] ? plans[0]->ctx : nullptr;
+    for (int i = 0; i < nlimbs; ++i) {
+        ntt_plan *pl = plans[i];
+        if (!pl || !a[i] || !b[i] || !ab[i]) return fail(NTT_ERR_INVALID, std::string(who) + ": null plan or array");
+        if (!pl->shard.empty()) return fail(NTT_ERR_UNSUPPORTED, std::string(who) + ": plans of a multi-device context shard rows, not limbs: call per slot with plans made on ntt_ctx_device(ctx, slot)");
+        if (pl->ctx != cx) return fail(NTT_ERR_INVALID, std::string(who) + ": every plan must come from the same context");
+        if (batch > pl->batch) return fail(NTT_ERR_INVALID, std::string(who) + ": batch exceeds a plan's capacity");
+        if (ab_stride < (pl->negacyclic ? (size_t)pl->n : 2 * (size_t)pl->n - 1))
+            return fail(NTT_ERR_INVALID, std::string(who) + ": output row stride below the row length");
+        for (int j = 0; j < i; ++j)
+            if (plans[j] == pl) return fail(NTT_ERR_INVALID, std::string(who) + ": a plan may appear once (its work buffers serve one limb at a time): give equal moduli one larger batch");
+        if (!is_device_ptr(a[i]) || !is_device_ptr(b[i]) || !is_device_ptr(ab[i]))
+            return fail(NTT_ERR_INVALID, std::string(who) + ": device arrays only");
+    }
+    std::lock_guard<std::mutex> lk(cx->mu);
+    HIP_TRY(hipSetDevice(cx->device));
+    int lanes = std::min(cx->nlanes, nlimbs);
+    if (cx->lane_limit > 0) lanes = std::min(lanes, cx->lane_limit);
+    for (int l = 1; l < lanes; ++l)
+        if (!cx->lane[l]) lanes = l;
+    hipStream_t main_stream = cx->stream;
+    if (lanes > 1) {
+        HIP_TRY(hipEventRecord(cx->fork_ev, main_stream));
+        for (int l = 1; l < lanes; ++l) HIP_TRY(hipStreamWaitEvent(cx->lane[l], cx->fork_ev, 0));
+    }
+    int rc = NTT_OK;
+    {
+        struct Restore {                                   // whatever ends the loop, the context gets its stream back
+            ntt_ctx *c;
+            hipStream_t s;
+            ~Restore() { c->stream = s; c->cur = s; }
+        } restore{cx, main_stream};
+        for (int i = 0; i < nlimbs && !rc; ++i) {
+            ntt_plan *pl = plans[i];
+            const int l = i % lanes;
+            cx->stream = l == 0 ? main_stream : cx->lane[l];    // the plan's launches follow ctx->stream
+            cx->cur = cx->stream;
+            const ntt_plan *shape = pl->wide ? pl->wide : pl;
+            // the limb has its plan's work buffers to itself (both lanes' halves): chunks up to lanes x chunk products
+            int chunk = shape->chunk * std::max(1, shape->lanes);
+            if (const char *e = std::getenv("NTT_AMD_LIMB_CHUNK")) chunk = std::max(1, std::min(chunk, std::atoi(e)));
+            const int nch = (batch + chunk - 1) / chunk;
+            chunk = (batch + nch - 1) / nch;                     // equal shares: no small last launch
+            WorkArea area{static_cast<uint32_t *>(shape->work0.ptr), static_cast<uint32_t *>(shape->work1.ptr), chunk};
+            const bool needs_area = shape->logL > kRowLog && !shape->fused;
+            rc = multiply_device_any(pl, a[i], b[i], ab[i], ab_stride, batch, needs_area ? &area : nullptr);
+        }
+    }
+    // join even after a failure: the next call must not find the lanes unordered
+    for (int l = 1; l < lanes; ++l) {
+        hipError_t e = hipEventRecord(cx->lane_done[l], cx->lane[l]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(main_stream, cx->lane_done[l], 0);
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(cx->lane[l]);
+            if (!rc) rc = fail(NTT_ERR_HIP, std::string("joining stream lanes: ") + hipGetErrorString(e));
+        }
+    }
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return NTT_OK;
+}
+NTT_CATCH_STATUS
+
 // The variant of ntt_poly_multiply_batched that allocates nothing (include/ntt_amd.h): device pointers only,
 // intermediates in this device's copy of the static scratch array, one stream lane, no kernel-timing events.
 int ntt_poly_multiply_batched_noalloc(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,

@@ -369,3 +369,85 @@ def test_object_lifetimes_return_their_device_memory(nt):
     for i in range(6):
         free = cycle(i)
     assert free >= base - (4 << 20), f"{(base - free) >> 20} MiB of device memory did not come back over 6 cycles"
+
+
+@pytest.mark.parametrize("n", [1000, 5000, 20000, 131072])
+def test_multiply_limbs_matches_per_limb_calls(nt, n):
+    """ntt_poly_multiply_limbs: several moduli in one call, each limb whole on a stream lane (lazy, wide-range and strict
+    primes side by side; L = 2048 -> the 4096-point row kernel, 16384 fused, 65536 and 2^18 through work buffers): every
+    row equals the per-limb ntt_poly_multiply_batched result, rows of the small sizes the oracle's."""
+    import torch
+    primes = [998244353, 469762049, 1224736769, 7340033, 104857601]
+    batch = 7 if n < 100000 else 3
+    rng = np.random.default_rng(n)
+    ctx = nt.Context(0)
+    plans = [ctx.plan(p, n, batch) for p in primes]
+    ha = [rng.integers(0, p, size=(batch, n), dtype=np.int64).astype(np.uint32) for p in primes]
+    hb = [rng.integers(0, p, size=(batch, n), dtype=np.int64).astype(np.uint32) for p in primes]
+    for x, p in zip(ha, primes):
+        x[0, :] = p - 1
+    for x, p in zip(hb, primes):
+        x[0, :] = p - 1
+    da = [torch.from_numpy(x.view(np.int32)).cuda() for x in ha]
+    db = [torch.from_numpy(x.view(np.int32)).cuda() for x in hb]
+    stride = 2 * n + 3
+    outs = [torch.full((batch, stride), -1, dtype=torch.int32, device="cuda") for _ in primes]
+    torch.cuda.synchronize()
+    for _ in range(2):
+        nt.multiply_limbs(plans, da, db, outs, batch, out_stride=stride)
+    ctx.synchronize()
+    for i, p in enumerate(primes):
+        got = outs[i].cpu().numpy().view(np.uint32)
+        assert np.all(got[:, 2 * n - 1:] == 0xFFFFFFFF), "wrote past the row"
+        want = plans[i].multiply(ha[i], hb[i], batch=batch)
+        assert np.array_equal(got[:, :2 * n - 1], want), (p, n)
+        if n <= 20000:
+            for r in (0, batch - 1):
+                assert np.array_equal(want[r], orc.poly_multiply(ha[i][r], hb[i][r], p)), (p, n, r)
+    # argument checks
+    with pytest.raises(nt.NttError) as e:
+        nt.multiply_limbs([plans[0], plans[0]], da[:2], db[:2], outs[:2], batch, out_stride=stride)      # a plan twice
+    assert e.value.code == nt.ERR_INVALID
+    with pytest.raises(nt.NttError):
+        nt.multiply_limbs(plans[:2], ha[:2], db[:2], outs[:2], batch, out_stride=stride)                 # host array
+    other = nt.Context(0)
+    foreign = other.plan(primes[1], n, batch)
+    with pytest.raises(nt.NttError):
+        nt.multiply_limbs([plans[0], foreign], da[:2], db[:2], outs[:2], batch, out_stride=stride)       # two contexts
+    small = ctx.plan(primes[0], n, batch - 1)
+    with pytest.raises(nt.NttError):
+        nt.multiply_limbs([small, plans[1]], da[:2], db[:2], outs[:2], batch, out_stride=stride)         # beyond a plan's capacity
+    other.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("n", [2048, 8192, 65536])
+def test_multiply_limbs_negacyclic(nt, n):
+    """The limbs of an x^n + 1 ring in one call: every row equals ntt_negacyclic_multiply_batched's (itself checked against
+    the folded oracle product in tests/test_gpu_negacyclic.py)."""
+    import torch
+    primes = [998244353, 469762049, 1224736769, 7340033, 104857601]
+    batch = 5
+    rng = np.random.default_rng(n + 1)
+    ctx = nt.Context(0)
+    plans = [ctx.negacyclic_plan(p, n, batch) for p in primes]
+    ha = [rng.integers(0, p, size=(batch, n), dtype=np.int64).astype(np.uint32) for p in primes]
+    hb = [rng.integers(0, p, size=(batch, n), dtype=np.int64).astype(np.uint32) for p in primes]
+    ha[0][0, :] = primes[0] - 1
+    hb[0][0, :] = primes[0] - 1
+    da = [torch.from_numpy(x.view(np.int32)).cuda() for x in ha]
+    db = [torch.from_numpy(x.view(np.int32)).cuda() for x in hb]
+    outs = [torch.full((batch, n + 2), -1, dtype=torch.int32, device="cuda") for _ in primes]
+    torch.cuda.synchronize()
+    nt.multiply_limbs(plans, da, db, outs, batch, out_stride=n + 2)
+    ctx.synchronize()
+    for i, p in enumerate(primes):
+        got = outs[i].cpu().numpy().view(np.uint32)
+        assert np.all(got[:, n:] == 0xFFFFFFFF), "wrote past the row"
+        assert np.array_equal(got[:, :n], plans[i].multiply(ha[i], hb[i], batch=batch)), (p, n)
+    # the fold itself, once, on the smallest size: c = (a * b)[0:n] - (a * b)[n:2n-1]
+    if n == 2048:
+        lin = orc.poly_multiply(ha[1][2], hb[1][2], primes[1]).astype(np.int64)
+        fold = (lin[:n] - np.concatenate([lin[n:], [0]])) % primes[1]
+        assert np.array_equal(outs[1][2, :n].cpu().numpy().view(np.uint32), fold.astype(np.uint32))
+    ctx.close()
