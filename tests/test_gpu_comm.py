@@ -90,3 +90,16 @@ def test_comm_rccl_mode_one_rank(nt):
         assert np.array_equal(dout.cpu().numpy().view(np.uint64), want)
     comm.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_comm_ranks_program(world):
+    """ntt_amd/comm_ranks (csrc/comm_ranks.cpp): the same in plain C++ -- N forked processes, a context and a host-mode
+    communicator each, the all-to-all through shared memory where an MPI program passes MPI_Alltoall; every rank
+    compares the large-modulus product at n = 2^17, a split transform of 2^20 points (forward, round trip) and a split
+    product with the results of its own single context."""
+    exe = os.path.join(os.path.dirname(HERE), "ntt_amd", "comm_ranks")
+    assert os.path.exists(exe), "build it with make -C ntt_amd/csrc"
+    r = subprocess.run([exe, str(world)], capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stdout + r.stderr[-2000:]
+    assert f"comm_ranks: {world} ranks, ok" in r.stdout
