@@ -283,14 +283,58 @@ int multiply_device(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64
     // equal chunks of at most 96 MiB per work buffer (48 products at L = 2^18): the intermediates of a launch
     // sequence stay inside the 256 MiB Infinity Cache (tools/sweep_batch64.py: 5.25 us per product at 32-48 per
     // launch, 5.6 at 128), and the work buffers do not grow with the batch
-    const int cap = (int)std::max<size_t>(1, std::min<size_t>((size_t)pl->batch, ((size_t)96 << 20) / ((size_t)L * 8)));
-    const int chunk = (batch + (batch + cap - 1) / cap - 1) / ((batch + cap - 1) / cap);      // equal shares, none above cap
-    int rc = pl->work0.ensure((size_t)cap * L * 8);
-    if (!rc) rc = pl->work1.ensure((size_t)cap * L * 8);
+    // Round 3: the chunks alternate between the context's two stream lanes, as in the 32-bit path -- the memory-bound
+    // column kernels of one chunk run beside the FP64-bound row kernel of the other (NTT_AMD_LANES64=1, read per call,
+    // keeps one lane).  Each lane has its own pair of work buffers; a lane's chunk is capped lower so that the
+    // intermediates of both lanes still fit the cache (NTT_AMD_CHUNK64 overrides the cap, for sweeps).
+    int want_lanes = std::min(cx->nlanes, 2);
+    if (cx->lane_limit > 0) want_lanes = std::min(want_lanes, cx->lane_limit);
+    if (want_lanes > 1 && !cx->lane[1]) want_lanes = 1;
+    if (const char *e = std::getenv("NTT_AMD_LANES64")) want_lanes = std::max(1, std::min(want_lanes, std::atoi(e)));
+    size_t cap_bytes = (size_t)(want_lanes > 1 ? 48 : 96) << 20;
+    int cap = (int)std::max<size_t>(1, std::min<size_t>((size_t)pl->batch, cap_bytes / ((size_t)L * 8)));
+    if (const char *e = std::getenv("NTT_AMD_CHUNK64")) cap = std::max(1, std::min(pl->batch, std::atoi(e)));
+    int nchunks = (batch + cap - 1) / cap;
+    const int lanes = std::min(want_lanes, nchunks);
+    if (lanes == 2 && (nchunks & 1) && nchunks <= 5) ++nchunks;          // a few chunks only: the same number on both lanes
+    const int chunk = (batch + nchunks - 1) / nchunks;                   // equal shares, none above cap
+    const size_t per_lane = (size_t)cap * L * 8;
+    int rc = pl->work0.ensure(per_lane * (size_t)want_lanes);
+    if (!rc) rc = pl->work1.ensure(per_lane * (size_t)want_lanes);
     if (rc) return rc;
-    uint64_t *w0 = static_cast<uint64_t *>(pl->work0.ptr), *w1 = static_cast<uint64_t *>(pl->work1.ptr);
     const int m = pl->nlevels;
-    for (int c0 = 0; c0 < batch; c0 += chunk) {
+    struct LaneJoin {                                                    // whatever ends the loop: lane 1 is joined, the context gets its stream back
+        ntt_ctx *cx;
+        hipStream_t main;
+        bool forked = false;
+        int join()
+        {
+            cx->cur = main;
+            if (!forked) return NTT_OK;
+            forked = false;
+            hipError_t e = hipEventRecord(cx->lane_done[1], cx->lane[1]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(main, cx->lane_done[1], 0);
+            if (e != hipSuccess) {
+                (void)hipStreamSynchronize(cx->lane[1]);
+                return fail(NTT_ERR_HIP, std::string("joining stream lanes: ") + hipGetErrorString(e));
+            }
+            return NTT_OK;
+        }
+        ~LaneJoin() { (void)join(); }
+    } lanes_guard{cx, s};
+    if (lanes > 1) {
+        HIP_TRY(hipEventRecord(cx->fork_ev, s));
+        lanes_guard.forked = true;
+        HIP_TRY(hipStreamWaitEvent(cx->lane[1], cx->fork_ev, 0));
+    }
+    const hipStream_t main_stream = s;
+    int ci = 0;
+    for (int c0 = 0; c0 < batch; c0 += chunk, ++ci) {
+        const int lane = ci % lanes;
+        s = lane ? cx->lane[1] : main_stream;
+        cx->cur = s;
+        uint64_t *w0 = reinterpret_cast<uint64_t *>(static_cast<char *>(pl->work0.ptr) + (size_t)lane * per_lane);
+        uint64_t *w1 = reinterpret_cast<uint64_t *>(static_cast<char *>(pl->work1.ptr) + (size_t)lane * per_lane);
         const unsigned cb = (unsigned)std::min(chunk, batch - c0);
         const uint64_t *ca = a + (size_t)c0 * n, *cbp = b + (size_t)c0 * n;
         uint64_t *cout = ab + (size_t)c0 * ab_stride;
@@ -323,6 +367,7 @@ int multiply_device(ntt_plan64 *pl, const uint64_t *a, const uint64_t *b, uint64
             cx->end();
         }
     }
+    if ((rc = lanes_guard.join())) return rc;
     HIP_TRY(hipGetLastError());
     if (int lrc_ = ntt::take_launch_error()) return lrc_;
     return NTT_OK;
