@@ -424,6 +424,30 @@ static void small_pass(ntt_plan *pl, int mode, const uint32_t *a0, const uint32_
     cx->end();
 }
 
+// Whatever ends a function that spreads its chunks over the stream lanes (a failed HIP call between fork and join
+// included), the context gets its own stream back as the launch target and every side lane that may hold work is
+// joined into it, so that the next call on the context never runs on a half-ordered stream.
+struct LaneJoin {
+    ntt_ctx *cx;
+    int forked = 0;                                   // side lanes 1 .. forked-1 were made to wait on the fork event
+    int join()
+    {
+        cx->cur = cx->stream;
+        int rc = NTT_OK;
+        for (int l = 1; l < forked; ++l) {
+            hipError_t e = hipEventRecord(cx->lane_done[l], cx->lane[l]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(cx->stream, cx->lane_done[l], 0);
+            if (e != hipSuccess) {
+                (void)hipStreamSynchronize(cx->lane[l]);     // last resort: order by waiting on the host
+                rc = fail(NTT_ERR_HIP, std::string("joining stream lanes: ") + hipGetErrorString(e));
+            }
+        }
+        forked = 0;
+        return rc;
+    }
+    ~LaneJoin() { if (forked || cx->cur != cx->stream) (void)join(); }
+};
+
 // a, b, ab: DEVICE pointers.  area == nullptr: the plan's work buffers and lanes.
 template <class MM>
 static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, uint32_t *ab,
@@ -478,29 +502,7 @@ static int multiply_device(ntt_plan *pl, const uint32_t *a, const uint32_t *b, u
     const int nchunks = (batch + chunk - 1) / chunk;
     int lanes = area ? 1 : std::min(std::min(pl->lanes, cx->nlanes), nchunks);
     if (cx->lane_limit > 0) lanes = std::min(lanes, cx->lane_limit);
-    // Whatever ends this function (a failed HIP call between fork and join included), the context gets
-    // its own stream back as the launch target and every side lane that may hold work is joined into it,
-    // so that the next call on the context never runs on a half-ordered stream.
-    struct LaneJoin {
-        ntt_ctx *cx;
-        int forked = 0;                                   // side lanes 1 .. forked-1 were made to wait on the fork event
-        int join()
-        {
-            cx->cur = cx->stream;
-            int rc = NTT_OK;
-            for (int l = 1; l < forked; ++l) {
-                hipError_t e = hipEventRecord(cx->lane_done[l], cx->lane[l]);
-                if (e == hipSuccess) e = hipStreamWaitEvent(cx->stream, cx->lane_done[l], 0);
-                if (e != hipSuccess) {
-                    (void)hipStreamSynchronize(cx->lane[l]);     // last resort: order by waiting on the host
-                    rc = fail(NTT_ERR_HIP, std::string("joining stream lanes: ") + hipGetErrorString(e));
-                }
-            }
-            forked = 0;
-            return rc;
-        }
-        ~LaneJoin() { if (forked || cx->cur != cx->stream) (void)join(); }
-    } lanes_guard{cx};
+    LaneJoin lanes_guard{cx};
     if (lanes > 1) {                                      // fork: side lanes start after prior work
         // ordering between the lanes is what keeps the results right: a failure here is an error, not a warning
         HIP_TRY(hipEventRecord(cx->fork_ev, cx->stream));
@@ -662,9 +664,27 @@ static int transform_device(ntt_plan *pl, const uint32_t *src, uint32_t *data, i
         small_pass<MM>(pl, inverse ? 2 : 1, src, nullptr, data, L, L, L, L, (unsigned)batch);
         return NTT_OK;
     }
-    uint32_t *w0 = static_cast<uint32_t *>(pl->work0.ptr);
     const int m = pl->nlevels;
-    for (int c0 = 0; c0 < batch; c0 += pl->chunk) {
+    // a batch of transforms alternates its chunks between the stream lanes like a batch of products (round 3): the
+    // memory-bound column and reordering passes of one chunk run beside the row pass of the other
+    ntt_ctx *cx = pl->ctx;
+    const int nchunks = (batch + pl->chunk - 1) / pl->chunk;
+    int lanes = std::min(std::min(pl->lanes, cx->nlanes), nchunks);
+    if (cx->lane_limit > 0) lanes = std::min(lanes, cx->lane_limit);
+    if (const char *e = std::getenv("NTT_AMD_TRANSFORM_LANES")) lanes = std::max(1, std::min(lanes, std::atoi(e)));
+    LaneJoin lanes_guard{cx};
+    if (lanes > 1) {
+        HIP_TRY(hipEventRecord(cx->fork_ev, cx->stream));
+        for (int l = 1; l < lanes; ++l) {
+            lanes_guard.forked = l + 1;
+            HIP_TRY(hipStreamWaitEvent(cx->lane[l], cx->fork_ev, 0));
+        }
+    }
+    int ci = 0;
+    for (int c0 = 0; c0 < batch; c0 += pl->chunk, ++ci) {
+        const int l = ci % lanes;
+        cx->cur = l == 0 ? cx->stream : cx->lane[l];
+        uint32_t *w0 = static_cast<uint32_t *>(pl->work0.ptr) + (size_t)l * pl->chunk * L;
         const unsigned cb = (unsigned)std::min(pl->chunk, batch - c0);
         const uint32_t *s = src + (size_t)c0 * L;
         uint32_t *d = data + (size_t)c0 * L;
@@ -690,7 +710,7 @@ static int transform_device(ntt_plan *pl, const uint32_t *src, uint32_t *data, i
                              j == 0, cb, 1);
         }
     }
-    return NTT_OK;
+    return lanes_guard.join();
 }
 
 // One transform of the plan's length from src to dst (DEVICE pointers on the plan's GPU, src == dst allowed), queued
