@@ -179,7 +179,11 @@ int ntt_negacyclic_multiply_batched(ntt_plan *plan, const uint32_t *a, const uin
  * main-montgomery.cc:297, :326-351) for any number of products; SURVEY 8f rank 2. */
 int ntt_poly_multiply_stream(ntt_plan *plan, const uint32_t *a, const uint32_t *b, uint32_t *ab,
                              size_t ab_stride, size_t count);
-/* Page-locked host memory for the call above (hipHostMalloc / hipHostFree). */
+/* Page-locked host memory for the call above (hipHostMalloc / hipHostFree).  Arrays from here are also used IN PLACE by
+ * a small ntt_poly_multiply_batched / poly_multiply call (at most 1 MiB per operand: one n = 2^17 product): 67 us per
+ * call; pageable arrays of such a call go through page-locked buffers of the context and a CPU memcpy each way: 108 us
+ * (128 through hipMemcpy; profiles/latency_r03c.txt).  Locking the caller's existing arrays in place (hipHostRegister)
+ * is not offered: it fails with `invalid argument` on the machines this was developed on. */
 int ntt_host_alloc(size_t bytes, void **ptr);
 int ntt_host_free(void *ptr);
 

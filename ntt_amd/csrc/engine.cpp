@@ -119,16 +119,31 @@ void DeviceBuffer::release()
     ptr = nullptr;
     bytes = 0;
 }
+int PinnedBuffer::ensure(size_t need)
+{
+    if (need <= bytes) return NTT_OK;
+    release();
+    hipError_t e = hipHostMalloc(&ptr, need, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        ptr = nullptr;
+        return fail(e == hipErrorOutOfMemory ? NTT_ERR_NOMEM : NTT_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
+    bytes = need;
+    return NTT_OK;
+}
+void PinnedBuffer::release()
+{
+    if (ptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+}
 
 // Device or host?  hipPointerGetAttributes knows the allocations of THIS HIP runtime.  A pointer
 // from another HIP runtime in the same process (PyTorch bundles its own libamdhip64; both sit on
 // one HSA runtime) is unknown to it, so fall back to the HSA pointer registry, which is shared.
-bool is_device_ptr(const void *p)
+// device memory by the HSA runtime's registry: what another HIP runtime in the process allocated is known there
+static bool hsa_device_ptr(const void *p)
 {
-    hipPointerAttribute_t at{};
-    hipError_t e = hipPointerGetAttributes(&at, p);
-    if (e == hipSuccess && (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged)) return true;
-    if (e != hipSuccess) (void)hipGetLastError();   // unregistered memory reports an error: clear it
     hsa_amd_pointer_info_t info{};
     info.size = sizeof(info);
     if (hsa_amd_pointer_info(const_cast<void *>(p), &info, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS)
@@ -137,6 +152,15 @@ bool is_device_ptr(const void *p)
     hsa_device_type_t dt = HSA_DEVICE_TYPE_CPU;
     if (hsa_agent_get_info(info.agentOwner, HSA_AGENT_INFO_DEVICE, &dt) != HSA_STATUS_SUCCESS) return false;
     return dt == HSA_DEVICE_TYPE_GPU;
+}
+
+bool is_device_ptr(const void *p)
+{
+    hipPointerAttribute_t at{};
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e == hipSuccess && (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged)) return true;
+    if (e != hipSuccess) (void)hipGetLastError();   // unregistered memory reports an error: clear it
+    return hsa_device_ptr(p);
 }
 
 // Page-locked host memory this HIP runtime knows (hipHostMalloc / hipHostRegister): device-accessible at the same address
@@ -957,6 +981,9 @@ try {
     ntt::crt_direct_release(ctx);
     ntt::stream_release(ctx);
     ctx->stage_a.release();
+    ctx->pin_a.release();
+    ctx->pin_b.release();
+    ctx->pin_out.release();
     ctx->stage_b.release();
     ctx->stage_out.release();
     for (auto &s : ctx->stamps) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
@@ -1156,43 +1183,84 @@ static int multiply_entry(ntt_plan *pl, const uint32_t *a, const uint32_t *b, ui
     // are used in place: the first pass reads the operands and the last pass writes the result over PCIe, which costs
     // less than three staging copies with a launch latency each when there is one product to move (93 -> 6x us per
     // n = 2^17 product, profiles/latency_r03.txt).  Larger calls stage as before (DMA beats loads over the link).
+    // PAGEABLE arrays of such a call (the harness's own: main-montgomery.cc:297 keeps a, b, ab in static arrays) go the
+    // same way through page-locked buffers of the context and a plain CPU memcpy each way: 13 us for both operands and
+    // 11 us for the result of an n = 2^17 product, where hipMemcpy from and to pageable memory takes 43 and 63 us
+    // (profiles/ubench_stage_r03.txt).  NTT_AMD_PAGEABLE_STAGE=0 (read per call) keeps the hipMemcpy staging.
     const bool zero_copy = in_bytes <= kZeroCopyBytes;
-    bool da = is_device_ptr(a) || (zero_copy && is_pinned_host_ptr(a)), db = is_device_ptr(b) || (zero_copy && is_pinned_host_ptr(b));
-    bool dab = is_device_ptr(ab);
-    const bool host_out_in_place = !dab && zero_copy && is_pinned_host_ptr(ab);
-    dab = dab || host_out_in_place;
-    const bool host_in_place = host_out_in_place || !is_device_ptr(a) || !is_device_ptr(b);
+    const bool own_pinned = zero_copy && [] { const char *e = std::getenv("NTT_AMD_PAGEABLE_STAGE"); return !(e && e[0] == '0'); }();
+    // one runtime query per array (each costs about a microsecond, more for memory the runtime does not know)
+    enum class Mem { Device, Pinned, Pageable };
+    auto classify = [](const void *p) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, p) == hipSuccess) {
+            if (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged) return Mem::Device;
+            if (at.type == hipMemoryTypeHost && at.devicePointer != nullptr) return Mem::Pinned;
+        } else {
+            (void)hipGetLastError();                       // unregistered memory reports an error: clear it
+        }
+        return hsa_device_ptr(p) ? Mem::Device : Mem::Pageable;   // memory of another runtime in the process
+    };
+    Mem ma = classify(a), mb = classify(b), mab = classify(ab);
     const uint32_t *pa = a, *pb = b;
     uint32_t *pab = ab;
+    bool copy_back = false;
+    if (own_pinned) {
+        if (ma == Mem::Pageable) {
+            if (int rc = cx->pin_a.ensure(in_bytes)) return rc;
+            std::memcpy(cx->pin_a.ptr, a, in_bytes);
+            pa = static_cast<const uint32_t *>(cx->pin_a.ptr);
+            ma = Mem::Pinned;
+        }
+        if (mb == Mem::Pageable) {
+            if (int rc = cx->pin_b.ensure(in_bytes)) return rc;
+            std::memcpy(cx->pin_b.ptr, b, in_bytes);
+            pb = static_cast<const uint32_t *>(cx->pin_b.ptr);
+            mb = Mem::Pinned;
+        }
+        if (mab == Mem::Pageable) {
+            if (int rc = cx->pin_out.ensure(out_elems * 4)) return rc;
+            pab = static_cast<uint32_t *>(cx->pin_out.ptr);
+            if (ab_stride != out_len) std::memcpy(pab, ab, out_elems * 4);      // keep the caller's bytes between rows
+            copy_back = true;
+            mab = Mem::Pinned;
+        }
+    }
+    const bool da = ma == Mem::Device || (zero_copy && ma == Mem::Pinned), db = mb == Mem::Device || (zero_copy && mb == Mem::Pinned);
+    const bool host_out_in_place = zero_copy && mab == Mem::Pinned;
+    const bool dab = mab == Mem::Device || host_out_in_place;
+    const bool host_in_place = host_out_in_place || ma != Mem::Device || mb != Mem::Device;
     if (!da) {
         int rc = cx->stage_a.ensure(in_bytes);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(cx->stage_a.ptr, a, in_bytes, hipMemcpyHostToDevice, cx->stream));
+        HIP_TRY(hipMemcpyAsync(cx->stage_a.ptr, pa, in_bytes, hipMemcpyHostToDevice, cx->stream));
         pa = static_cast<const uint32_t *>(cx->stage_a.ptr);
     }
     if (!db) {
         int rc = cx->stage_b.ensure(in_bytes);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(cx->stage_b.ptr, b, in_bytes, hipMemcpyHostToDevice, cx->stream));
+        HIP_TRY(hipMemcpyAsync(cx->stage_b.ptr, pb, in_bytes, hipMemcpyHostToDevice, cx->stream));
         pb = static_cast<const uint32_t *>(cx->stage_b.ptr);
     }
+    uint32_t *const host_dst = pab;                        // where the result goes on the host side (the caller's array, or pin_out)
     if (!dab) {
         int rc = cx->stage_out.ensure(out_elems * 4);
         if (rc) return rc;
         pab = static_cast<uint32_t *>(cx->stage_out.ptr);
         if (ab_stride != out_len)      // keep the caller's bytes between rows: entries >= 2n-1 are not ours
-            HIP_TRY(hipMemcpyAsync(pab, ab, out_elems * 4, hipMemcpyHostToDevice, cx->stream));
+            HIP_TRY(hipMemcpyAsync(pab, host_dst, out_elems * 4, hipMemcpyHostToDevice, cx->stream));
     }
     int rc = multiply_device_any(pl, pa, pb, pab, ab_stride, batch);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     if (int lrc_ = ntt::take_launch_error()) return lrc_;
     if (!dab) {
-        HIP_TRY(hipMemcpyAsync(ab, pab, out_elems * 4, hipMemcpyDeviceToHost, cx->stream));
+        HIP_TRY(hipMemcpyAsync(host_dst, pab, out_elems * 4, hipMemcpyDeviceToHost, cx->stream));
         if (int src_ = sync_stream(cx)) return src_;
     } else if (!da || !db || host_in_place) {
         if (int src_ = sync_stream(cx)) return src_;   // host arrays: the call returns when they may be reused / are complete
     }
+    if (copy_back) std::memcpy(ab, cx->pin_out.ptr, out_elems * 4);
     return NTT_OK;
 }
 

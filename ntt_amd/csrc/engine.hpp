@@ -36,6 +36,14 @@ struct DeviceBuffer {
     void release();
 };
 
+// Page-locked host memory owned by a context (hipHostMalloc: mapped into the device's address space).
+struct PinnedBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need);
+    void release();
+};
+
 // Buffers and per-prime plans of ntt_crt_multiply, cached per context for the last n used.
 struct CrtWorkspace {
     int n = 0, batch = 0;                 // plans hold `batch` products of length n
@@ -158,6 +166,7 @@ struct ntt_ctx {
         int n = 0, batch = 0;
     } crt_direct;
     ntt::DeviceBuffer stage_a, stage_b, stage_out;   // host-pointer staging
+    ntt::PinnedBuffer pin_a, pin_b, pin_out;         // small calls on pageable arrays: CPU memcpy into / out of these, kernels work on them in place
     ntt::StreamState *stream_state = nullptr;        // ntt_poly_multiply_stream (stream.cpp)
 };
 

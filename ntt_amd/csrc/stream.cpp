@@ -42,25 +42,6 @@ struct JoinGuard {
     }
 };
 
-struct PinnedBuffer {
-    void *ptr = nullptr;
-    size_t bytes = 0;
-    int ensure(size_t need)
-    {
-        if (need <= bytes) return NTT_OK;
-        release();
-        HIP_TRY(hipHostMalloc(&ptr, need, hipHostMallocDefault));
-        bytes = need;
-        return NTT_OK;
-    }
-    void release()
-    {
-        if (ptr) (void)hipHostFree(ptr);
-        ptr = nullptr;
-        bytes = 0;
-    }
-};
-
 struct StreamState {
     hipStream_t h2d = nullptr, d2h = nullptr;
     bool own_d2h = false;

@@ -451,3 +451,40 @@ def test_multiply_limbs_negacyclic(nt, n):
         fold = (lin[:n] - np.concatenate([lin[n:], [0]])) % primes[1]
         assert np.array_equal(outs[1][2, :n].cpu().numpy().view(np.uint32), fold.astype(np.uint32))
     ctx.close()
+
+
+def test_small_calls_on_pageable_arrays(nt, monkeypatch):
+    """poly_multiply / ntt_poly_multiply_batched on the harness's kind of arrays: pageable ones go through page-locked
+    buffers of the context and a CPU memcpy each way (NTT_AMD_PAGEABLE_STAGE=0: the hipMemcpy staging); page-locked and
+    pageable arrays mixed in one call; a row stride with a gap keeps the caller's bytes."""
+    p = 998244353
+    rng = np.random.default_rng(77)
+    ctx = nt.Context(0)
+    for n, batch in ((131072, 1), (30000, 3), (5, 2)):
+        a = rng.integers(0, p, size=(batch, n), dtype=np.int64).astype(np.uint32)
+        b = rng.integers(0, p, size=(batch, n), dtype=np.int64).astype(np.uint32)
+        want = np.stack([orc.poly_multiply(a[r], b[r], p) for r in range(batch)])
+        plan = ctx.plan(p, n, batch)
+        stride = 2 * n + 5
+        for stage in ("1", "0"):
+            monkeypatch.setenv("NTT_AMD_PAGEABLE_STAGE", stage)
+            for _ in range(2):                                  # twice: the context's buffers are reused
+                out = np.full((batch, stride), 0xABCD1234, dtype=np.uint32)
+                plan.multiply(a, b, out=out, batch=batch, out_stride=stride)
+                assert np.array_equal(out[:, :2 * n - 1], want), (n, stage)
+                assert np.all(out[:, 2 * n - 1:] == 0xABCD1234), "bytes between the rows were overwritten"
+        monkeypatch.delenv("NTT_AMD_PAGEABLE_STAGE")
+        ha = nt.host_array((batch, n))
+        ha[...] = a
+        mixed = np.zeros((batch, 2 * n - 1), dtype=np.uint32)   # page-locked a, pageable b and result
+        plan.multiply(ha, b, out=mixed, batch=batch)
+        assert np.array_equal(mixed, want)
+        hout = nt.host_array((batch, 2 * n - 1))                # pageable operands, page-locked result
+        plan.multiply(a, b, out=hout, batch=batch)
+        assert np.array_equal(hout, want)
+        plan.close()
+    # the reference's own entry point on int arrays
+    ia = rng.integers(0, p, size=70000, dtype=np.int64).astype(np.int32)
+    ib = rng.integers(0, p, size=70000, dtype=np.int64).astype(np.int32)
+    assert np.array_equal(nt.poly_multiply(ia, ib, p).view(np.uint32), orc.poly_multiply(ia.view(np.uint32), ib.view(np.uint32), p))
+    ctx.close()

@@ -66,3 +66,4 @@ t0 = time.perf_counter()
 for _ in range(200):
     call()
 print("poly_multiply(pinned int arrays) n = %6d: %.1f us per call" % (n, (time.perf_counter() - t0) / 200 * 1e6), flush=True)
+
