@@ -1056,8 +1056,10 @@ static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_ki
         if (e[0] == '0') pl->wide8 = false;
     // forward column pass: the register kernel wins in a full launch, the LDS-staged one (four times the
     // workgroups, a quarter of the work per thread) when a launch holds a few products only
-    // (single product: 9.7 -> 8.2 us, tools/time_single.py)
-    pl->col16_fwd = batch <= 4;
+    // (single product: 9.7 -> 8.2 us, tools/time_single.py).  The Barrett kernels always take the LDS-staged one: their
+    // 8-byte twiddles put the 64-point register kernel's root table beyond the SGPR file (150+ spilled), and its forward
+    // pass takes 1.46 us per product where the staged kernel takes 0.80 (391 k -> 435 k products/s, bench.py --barrett)
+    pl->col16_fwd = batch <= 4 || modmul_kind == NTT_MODMUL_BARRETT;
     if (const char *e = std::getenv("NTT_AMD_COL16")) {
         const int v = std::atoi(e);
         pl->col16_fwd = v & 1;

@@ -176,7 +176,9 @@ template <class MM, bool LAZY, int LOGN1, bool WIDE = false>
 static void launch_col_t(bool inverse, bool half_in, const ColArgs<MM> &a, const ModParams &mp,
                          dim3 grid, hipStream_t s)
 {
-    if constexpr (LOGN1 >= 5) {
+    // Montgomery only: with Barrett's 8-byte twiddles the column's table alone takes 126 registers and the pipelined
+    // kernel spills (148 VGPRs to scratch; 392 k -> 261 k products/s at the headline shape)
+    if constexpr (LOGN1 >= 5 && MM::kMontgomery) {
         if (!inverse && half_in && a.loop_batch && !a.twist && !a.canon && walk_prefetch()) {
             hipLaunchKernelGGL((col_walk_prefetch_kernel<MM, LAZY, LOGN1, WIDE>), grid, dim3(256), 0, s, a, mp);
             return;
