@@ -185,6 +185,31 @@ struct Mont32 {
         return mul_tw(u - v + bound, w, m);
 #endif
     }
+    // d0 * w0 + d1 * w1 mod p in [0, 2p) with ONE reduction: both signed products go into the same 64-bit accumulator.
+    // d0, d1: signed differences of two values in [0, bound), bound <= min(2p, 2^31); w0, w1: CENTRED table entries,
+    // |w| <= p / 2 (center_tw).  |d0 w0 + d1 w1| < 2 * 2p * p / 2 = 2p^2 <= p * 2^31 (p < 2^30 lazy; strict: < p^2 < p * 2^31),
+    // so with the addend p * 2^31 the sum lies in (0, 2p^2 + p * 2^31) below p * 2^32 and redc_lazy applies.  This is what
+    // lets two radix-2 stages run as one radix-4 step: the outputs (a - c) w^j +- i (b - d) w^j of the difference side
+    // cost two multiply-adds and one reduction each instead of a reduced product, a modular add and another product.
+    // The twiddles are scalar operands, the addend a vector pair (one scalar source per VOP3 on gfx950).
+    static NTT_HD uint32_t mul2_acc(int32_t d0, int32_t w0, int32_t d1, int32_t w1, const ModParams &m)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint64_t C = (uint64_t)m.p << 31;
+        uint64_t T0, T1, carry;
+        asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(T0), "=s"(carry) : "v"(d0), "s"(w0), "v"(C));
+        asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(T1), "=s"(carry) : "v"(d1), "s"(w1), "v"(T0));
+        return redc_lazy(T1, m);
+#else
+        const int64_t T = (int64_t)d0 * w0 + (int64_t)d1 * w1 + (int64_t)((uint64_t)m.p << 31);
+        return redc_lazy((uint64_t)T, m);
+#endif
+    }
+    // table entry w * R mod p in [0, p) -> the representative in (-p / 2, p / 2]
+    static NTT_HD int32_t center_tw(tw_t w, const ModParams &m)
+    {
+        return w > (m.p >> 1) ? (int32_t)(w - m.p) : (int32_t)w;
+    }
     // a*b*R^-1 mod p in [0, 2p); a any u32, b < p (or a*b < 2^32 * p)
     static NTT_HD uint32_t mul_raw(uint32_t a, uint32_t b, const ModParams &m)
     {
