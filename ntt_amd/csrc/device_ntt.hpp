@@ -185,8 +185,15 @@ struct WidePlan {
 // kind[s] = 1: stages s and s + 1 together; 2: the second stage of such a step; 0: a radix-2 stage.  Never the HALF opening
 // stage, never a pair whose second stage is a loose closing stage (its radix-2 form is two instructions per butterfly).
 #ifndef NTT_ACC4
-#define NTT_ACC4 1
+#define NTT_ACC4 1                       // 2: the sum side through the accumulator as well (measured -0.7 %, see reg_ntt)
 #endif
+// a + b + c as ONE instruction (v_add3_u32; the compiler splits the C++ form into two adds when c is a scalar)
+__device__ __forceinline__ int32_t add3_i32(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return (int32_t)r;
+}
 template <class MM, bool WIDE>
 constexpr bool acc4_enabled() { return NTT_ACC4 && MM::kMontgomery && !WIDE; }
 template <int LOGN, bool HALF, bool LOOSE>
@@ -207,6 +214,90 @@ struct Acc4Plan {
         }
     }
 };
+
+// Stages s and s + 1 of reg_ntt as one radix-4 step (see there).
+template <class MM, bool LAZY, int LOGN>
+__device__ __forceinline__ void acc4_step(uint32_t (&x)[1 << LOGN], const Roots64<MM> &roots, const ModParams &m, const int s)
+{
+    using O = Ops<MM, LAZY>;
+    constexpr int N = 1 << LOGN;
+    const int half = N >> (s + 1);
+    const int step = 32 / half;
+    const int hq = half / 2;
+    auto W = [&](int k) -> int32_t {
+        k &= 63;
+        const int32_t c = MM::center_tw(roots.w[k & 31], m);
+        return (k & 32) ? -c : c;
+    };
+#pragma unroll
+    for (int blk = 0; blk < N; blk += 2 * half) {
+#pragma unroll
+        for (int j = 0; j < hq; ++j) {
+            const int ia = blk + j, ib = ia + hq, ic = ia + half, id = ic + hq;
+            const uint32_t a = x[ia], b = x[ib], c = x[ic], d = x[id];
+            const int32_t d0 = (int32_t)(a - c), d1 = (int32_t)(b - d);
+#if NTT_ACC4 >= 2
+            // the sum side through the accumulator as well: e = a + c - bound and f = b + d - bound lie in
+            // [-bound, bound) like the differences (one three-operand add each), and
+            // x[i] = e * 1 + f * 1, x[i + half / 2] = e w^(2j) - f w^(2j): 10 instructions instead of 13, but 10
+            // half-rate ones instead of 3 -- row kernel 1897 -> 1761 instructions, 570 -> 566 k products/s
+            // (profiles/ab_acc4b_r03.txt): not the default
+            const int32_t e = add3_i32(a, c, 0u - O::bound(m)), f = add3_i32(b, d, 0u - O::bound(m));
+            const uint32_t y0 = MM::mul2_acc(e, W(0), f, W(0), m);
+            const uint32_t y1 = MM::mul2_acc(e, W(2 * j * step), f, W(2 * j * step + 32), m);
+            x[ia] = LAZY ? y0 : csub(y0, m.p);
+            x[ib] = LAZY ? y1 : csub(y1, m.p);
+#else
+            const uint32_t s0 = O::add(a, c, m), s1 = O::add(b, d, m);
+            x[ia] = O::add(s0, s1, m);
+            x[ib] = j == 0 ? O::sub(s0, s1, m) : O::mul_tw_diff(s0, s1, roots.w[2 * j * step], m);
+#endif
+            const uint32_t y2 = MM::mul2_acc(d0, W(j * step), d1, W((j + hq) * step), m);
+            const uint32_t y3 = MM::mul2_acc(d0, W(3 * j * step), d1, W((3 * j + hq) * step + 32), m);
+            x[ic] = LAZY ? y2 : csub(y2, m.p);
+            x[id] = LAZY ? y3 : csub(y3, m.p);
+        }
+    }
+}
+
+// A 16-point transform (reg_ntt<4>) TOGETHER with the multiplication of output k by a per-lane twiddle t_k that follows
+// it in the row passes (output 0 is not multiplied).  Stages 0 and 1 are the radix-4 step above; stages 2 and 3 are four
+// 4-point transforms with trivial roots (1, i), and with a, b, c, d the inputs of one of them its outputs are
+//   k         : ((a + c) + (b + d)) t_k            k + 8  : ((a + c) - (b + d)) t_(k+8)
+//   k + 4     : (a - c) t_(k+4) + (b - d) (i t_(k+4))        k + 12 : (a - c) t_(k+12) + (b - d) (-i t_(k+12))
+// so the two outputs of the difference side are two multiply-adds and one reduction each (Mont32::mul2_acc_v) when the
+// table also holds the ROTATED entries i t_k, -i t_k: 24 instructions per four points with their twiddles instead of 29.
+// tw(k): the plain table entry (Montgomery form in [0, p)) of output k, asked for k = 1, 2, 3, 8 ... 11;
+// t2(q): the pair { centred entry, centred rotated entry } of the q-th output of the difference side, q = 0 ... 7 for
+// k = 4, 5, 6, 7, 12, 13, 14, 15 (engine.cpp: rotated_table).  Outputs in natural order, below `bound` (output 0 tight).
+template <class MM, bool LAZY, class TW, class T2>
+__device__ __forceinline__ void reg_ntt16_tw(uint32_t (&x)[16], const Roots64<MM> &roots, const ModParams &m,
+                                             TW &&tw, T2 &&t2)
+{
+    using O = Ops<MM, LAZY>;
+    static_assert(MM::kMontgomery, "the accumulated products are Montgomery products");
+    acc4_step<MM, LAZY, 4>(x, roots, m, 0);
+#if NTT_FUSE_SCHED
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    uint32_t y[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int k = bitrev_c(4 * g, 4);                         // 0, 2, 1, 3
+        const uint32_t a = x[4 * g], b = x[4 * g + 1], c = x[4 * g + 2], d = x[4 * g + 3];
+        const uint32_t s0 = O::add(a, c, m), s1 = O::add(b, d, m);
+        const int32_t d0 = (int32_t)(a - c), d1 = (int32_t)(b - d);
+        y[k] = k == 0 ? O::add(s0, s1, m) : O::mul_tw(s0 + s1, tw(k), m);
+        y[k + 8] = O::mul_tw_diff(s0, s1, tw(k + 8), m);
+        const uint2 ta = t2(k), tb = t2(k + 4);
+        const uint32_t y4 = MM::mul2_acc_v(d0, (int32_t)ta.x, d1, (int32_t)ta.y, m);
+        const uint32_t y12 = MM::mul2_acc_v(d0, (int32_t)tb.x, d1, (int32_t)tb.y, m);
+        y[k + 4] = LAZY ? y4 : csub(y4, m.p);
+        y[k + 12] = LAZY ? y12 : csub(y12, m.p);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = y[i];
+}
 
 // In-register N-point transform, N = 2^LOGN <= 64: natural order in, natural order out,
 // X[k] = sum_j x[j] * w^(jk) with w = roots.w[32/(N/2)] (i.e. the primitive N-th root whose
@@ -251,28 +342,7 @@ __device__ __forceinline__ void reg_ntt(uint32_t (&x)[1 << LOGN], const Roots64<
             // table, computed on the scalar unit; an index of 32 and above is the negated entry.
             if (ap.kind[acc4_enabled<MM, WIDE>() ? s : 0] == 2) continue;             // second stage of a radix-4 step: done
             if (ap.kind[acc4_enabled<MM, WIDE>() ? s : 0] == 1) {
-                const int hq = half / 2;
-                auto W = [&](int k) -> int32_t {
-                    k &= 63;
-                    const int32_t c = MM::center_tw(roots.w[k & 31], m);
-                    return (k & 32) ? -c : c;
-                };
-#pragma unroll
-                for (int blk = 0; blk < N; blk += 2 * half) {
-#pragma unroll
-                    for (int j = 0; j < hq; ++j) {
-                        const int ia = blk + j, ib = ia + hq, ic = ia + half, id = ic + hq;
-                        const uint32_t a = x[ia], b = x[ib], c = x[ic], d = x[id];
-                        const uint32_t s0 = O::add(a, c, m), s1 = O::add(b, d, m);
-                        const int32_t d0 = (int32_t)(a - c), d1 = (int32_t)(b - d);
-                        x[ia] = O::add(s0, s1, m);
-                        x[ib] = j == 0 ? O::sub(s0, s1, m) : O::mul_tw_diff(s0, s1, roots.w[2 * j * step], m);
-                        const uint32_t y2 = MM::mul2_acc(d0, W(j * step), d1, W((j + hq) * step), m);
-                        const uint32_t y3 = MM::mul2_acc(d0, W(3 * j * step), d1, W((3 * j + hq) * step + 32), m);
-                        x[ic] = LAZY ? y2 : csub(y2, m.p);
-                        x[id] = LAZY ? y3 : csub(y3, m.p);
-                    }
-                }
+                acc4_step<MM, LAZY, LOGN>(x, roots, m, s);
                 continue;
             }
         }

@@ -204,6 +204,26 @@ static std::vector<typename MM::tw_t> power_table(uint32_t w, uint32_t rows, uin
     return t;
 }
 
+// The second table of a fused forward row pass (reg_ntt16_tw, device_ntt.hpp): for the q-th output of the difference
+// side, k = 4, 5, 6, 7, 12, 13, 14, 15, entry [q][i] is the pair { w^(i*k), rot * w^(i*k) } with rot = i4 for k < 8 and
+// -i4 above (i4 = the primitive fourth root the transform uses), both as CENTRED Montgomery forms in (-p / 2, p / 2]:
+// one 8-byte load per output.
+static std::vector<uint32_t> rotated_table(uint32_t w, uint32_t cols, uint32_t i4, const ModParams &mp)
+{
+    std::vector<uint32_t> t((size_t)16 * cols);
+    for (uint32_t q = 0; q < 8; ++q) {
+        const uint32_t k = q < 4 ? q + 4 : q + 8;
+        const uint32_t wk = h_powmod(w, k, mp.p), rot = q < 4 ? i4 : mp.p - i4;
+        uint32_t cur = 1;
+        for (uint32_t i = 0; i < cols; ++i) {
+            t[2 * ((size_t)q * cols + i)] = (uint32_t)Mont32::center_tw(Mont32::make_tw(cur, mp), mp);
+            t[2 * ((size_t)q * cols + i) + 1] = (uint32_t)Mont32::center_tw(Mont32::make_tw(h_mulmod(cur, rot, mp.p), mp), mp);
+            cur = h_mulmod(cur, wk, mp.p);
+        }
+    }
+    return t;
+}
+
 template <class MM>
 static std::vector<unsigned char> bytes_of_tw(uint32_t v, const ModParams &mp)
 {
@@ -326,7 +346,15 @@ static int build_tables(ntt_plan *pl)
     if (rc) return rc;
     rc = upload_table<MM>(pl, power_table<MM>(iw4096, 16, 256, 1, mp), &pl->itwA);
     if (rc) return rc;
-    return upload_table<MM>(pl, power_table<MM>(iw256, 16, 16, 1, mp), &pl->itwB);
+    rc = upload_table<MM>(pl, power_table<MM>(iw256, 16, 16, 1, mp), &pl->itwB);
+    if (rc) return rc;
+    if constexpr (MM::kMontgomery) {
+        const uint32_t i4 = h_powmod(wL, L / 4, p);
+        rc = upload_table<Mont32>(pl, rotated_table(w4096, 256, i4, mp), &pl->twA2);
+        if (rc) return rc;
+        rc = upload_table<Mont32>(pl, rotated_table(w256, 16, i4, mp), &pl->twB2);
+    }
+    return rc;
 }
 
 // ---- launch sequences -----------------------------------------------------------------------------
@@ -393,6 +421,8 @@ static RowArgs<MM> fill_row(ntt_plan *pl, const uint32_t *a0, const uint32_t *b0
     a.twB = static_cast<const typename MM::tw_t *>(pl->twB);
     a.itwA = static_cast<const typename MM::tw_t *>(pl->itwA);
     a.itwB = static_cast<const typename MM::tw_t *>(pl->itwB);
+    a.twA2 = static_cast<const uint2 *>(pl->twA2);
+    a.twB2 = static_cast<const uint2 *>(pl->twB2);
     fill_roots<MM>(a.roots, pl->roots);
     fill_roots<MM>(a.iroots, pl->iroots);
     return a;

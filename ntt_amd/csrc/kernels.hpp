@@ -53,6 +53,11 @@ struct RowArgs {
     const typename MM::tw_t *twA, *twB;          // forward [16][256], [16][16]
     const typename MM::tw_t *itwA, *itwB;        // inverse
     Roots64<MM> roots, iroots;
+    // Montgomery plans outside the wide range: the forward passes of row_mul_kernel run their last two stages together
+    // with the twiddles (reg_ntt16_tw) and read the entries of outputs 4 ... 7, 12 ... 15 from these instead:
+    // [8][256] and [8][16] pairs { centred entry, centred rotated entry (times i, resp. -i) } of the q-th such output
+    // (engine.cpp: rotated_table).  nullptr otherwise.
+    const uint2 *twA2, *twB2;
 };
 
 // A whole product of transform length L = 4096 in the row kernel (no column level): zero padding

@@ -205,6 +205,19 @@ struct Mont32 {
         return redc_lazy((uint64_t)T, m);
 #endif
     }
+    // the same with per-lane table entries (vector operands; the addend of the first multiply-add is then the scalar pair)
+    static NTT_HD uint32_t mul2_acc_v(int32_t d0, int32_t w0, int32_t d1, int32_t w1, const ModParams &m)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint64_t C = (uint64_t)m.p << 31;
+        uint64_t T0, T1, carry;
+        asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(T0), "=s"(carry) : "v"(d0), "v"(w0), "s"(C));
+        asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(T1), "=s"(carry) : "v"(d1), "v"(w1), "v"(T0));
+        return redc_lazy(T1, m);
+#else
+        return mul2_acc(d0, w0, d1, w1, m);
+#endif
+    }
     // table entry w * R mod p in [0, p) -> the representative in (-p / 2, p / 2]
     static NTT_HD int32_t center_tw(tw_t w, const ModParams &m)
     {

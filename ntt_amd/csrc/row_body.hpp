@@ -5,16 +5,10 @@
 
 // Ablation switches for timing experiments (tools/ablate_row.sh); never defined in the shipped build:
 //   NTT_ABL_NODATA  row kernels take synthetic inputs instead of global loads and skip the store
-//   NTT_ABL_NOTW    4-step/row twiddles come from the SGPR root table instead of global loads
+//   NTT_ABL_NOTW    row twiddles are not loaded (RowTable::at returns a constant)
 //   NTT_ABL_NOLDS   the LDS exchanges (and their barriers) are skipped
 //   NTT_ABL_VEC4    16-byte global accesses from the wrong positions (what a permuted hand-off layout would allow):
 //                   +0.5 % end to end (round 2), so the dword accesses are not what the row kernel waits for
-#if defined(NTT_ABL_NOTW)
-#define NTT_TW(tab, idx) a.roots.w[(idx) & 31]
-#else
-#define NTT_TW(tab, idx) (tab)[idx]
-#endif
-
 #if defined(NTT_ABL_NOLDS)
 #define NTT_LDS_ST(addr, v) asm volatile("" ::"v"(v))
 #define NTT_LDS_LD(dst, addr) asm volatile("" : "+v"(dst))
@@ -25,12 +19,54 @@
 #define NTT_BARRIER() __syncthreads()
 #endif
 
+#ifndef NTT_ROW_FUSE_TW
+#define NTT_ROW_FUSE_TW 3                // bit 0: first pass ([16][256] table), bit 1: second pass ([16][16] table)
+#endif
+
 namespace ntt {
 
 constexpr int kLdsWords = kRowLen + kRowLen / 16;      // 4352 dwords = 17 KiB
 
 __device__ __forceinline__ uint32_t P1(uint32_t i) { return i + ((i >> 8) << 4); }
 __device__ __forceinline__ uint32_t P2(uint32_t i) { return i + (i >> 4); }
+
+// Table reads of the row passes go through buffer descriptors (device_ntt.hpp): entry (k, lane) of a [16][cols] table is
+// reached as lane offset + scalar offset k * cols * sizeof(entry), so no table or row access costs a vector address
+// computation (the 64-bit pointer forms needed ~35 of them per wave).
+template <class TW>
+struct RowTable {
+    bufrsrc_t r;
+    uint32_t lane;                                    // byte offset of this lane's column
+    template <int COLS>
+    __device__ __forceinline__ TW at(int k) const
+    {
+#if defined(NTT_ABL_NOTW)
+        return TW{};
+#else
+        return buf_load_tw<TW>(r, lane, (uint32_t)k * COLS * (uint32_t)sizeof(TW));
+#endif
+    }
+};
+template <class TW>
+__device__ __forceinline__ RowTable<TW> row_table(const TW *base, uint32_t rows, uint32_t cols, uint32_t col)
+{
+    return RowTable<TW>{make_buf(base, rows * cols * (uint32_t)sizeof(TW)), col * (uint32_t)sizeof(TW)};
+}
+// the pair tables of the fused passes ([8][cols] uint2)
+struct RowTable2 {
+    bufrsrc_t r;
+    uint32_t lane;
+    template <int COLS>
+    __device__ __forceinline__ uint2 at(int q) const
+    {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane, (int)((uint32_t)q * COLS * 8u), 0);
+        return make_uint2(v[0], v[1]);
+    }
+};
+__device__ __forceinline__ RowTable2 row_table2(const uint2 *base, uint32_t cols, uint32_t col)
+{
+    return RowTable2{make_buf(base, 8u * cols * 8u), col * 8u};
+}
 
 // WIDE (p < 2^29, device_ntt.hpp): the loose 16-point transforms keep sums unreduced up to 4p and hand out values below
 // 8p; what is not multiplied next is brought back below 2p (tighten_wide).  Inputs are below 2p as always.
@@ -40,32 +76,81 @@ __device__ __forceinline__ uint32_t row_tighten(uint32_t x, const ModParams &m, 
     return WIDE ? tighten_wide(x, m) : csub(x, bound);
 }
 
+// One fused pass: the table entries are requested first, as one batch in front of the arithmetic (the scheduling barrier
+// keeps them there: left alone, the compiler issued every table load of the kernel directly in front of its use, each
+// with a full wait -- 530 k instead of 570 k products/s).
+template <class MM, bool LAZY, int COLS>
+__device__ __forceinline__ void fused_pass(uint32_t (&x)[16], const Roots64<MM> &roots, const ModParams &m,
+                                           const RowTable<typename MM::tw_t> &tab, const RowTable2 &tab2)
+{
+    typename MM::tw_t tv[16];
+    uint2 t2[8];
+#pragma unroll
+    for (int k = 1; k < 16; ++k)
+        if ((k & 4) == 0) tv[k] = tab.template at<COLS>(k);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t2[q] = tab2.at<COLS>(q);
+    __builtin_amdgcn_sched_barrier(0);
+    reg_ntt16_tw<MM, LAZY>(x, roots, m, [&](int k) { return tv[k]; }, [&](int q) { return t2[q]; });
+}
+
+// x[k] *= table entry k (k >= 1; x[0] is only brought into range), the entries requested as one batch
+template <class MM, bool LAZY, bool WIDE, int COLS>
+__device__ __forceinline__ void twiddle_pass(uint32_t (&x)[16], const ModParams &m, const RowTable<typename MM::tw_t> &tab)
+{
+    using O = Ops<MM, LAZY>;
+    typename MM::tw_t tv[16];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) tv[k] = tab.template at<COLS>(k);
+    __builtin_amdgcn_sched_barrier(0);
+    x[0] = row_tighten<WIDE>(x[0], m, O::bound(m));
+#pragma unroll
+    for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], tv[k], m);
+}
+
 // x[j] = row[t + 256*j] on entry; on exit x[k] = spectrum at position 16*t + k.
-template <class MM, bool LAZY, bool WIDE = false>
+// FUSE (row_mul_kernel of the Montgomery plans outside the wide range): the first two passes run their last two stages
+// together with the twiddles that follow (reg_ntt16_tw, a.twA2 / a.twB2).
+template <class MM, bool LAZY, bool WIDE = false, bool FUSE = false>
 __device__ __forceinline__ void row_forward(uint32_t (&x)[16], uint32_t *lds, const uint32_t t,
                                             const RowArgs<MM> &a, const ModParams &m)
 {
     using O = Ops<MM, LAZY>;
-    reg_ntt<MM, LAZY, 4, false, true, WIDE>(x, a.roots, m);      // loose: 15 of 16 outputs are multiplied next
-    x[0] = row_tighten<WIDE>(x[0], m, O::bound(m));
+    static_assert(!FUSE || (MM::kMontgomery && !WIDE), "the fused passes are Montgomery passes outside the wide range");
+    using tw_t = typename MM::tw_t;
+    const RowTable<tw_t> tA = row_table(a.twA, 16, 256, t);
+    if constexpr (FUSE && (NTT_ROW_FUSE_TW & 1)) {
+        const RowTable2 tA2 = row_table2(a.twA2, 256, t);
+        fused_pass<MM, LAZY, 256>(x, a.roots, m, tA, tA2);
+    } else {
+        reg_ntt<MM, LAZY, 4, false, true, WIDE>(x, a.roots, m);      // loose: 15 of 16 outputs are multiplied next
+        x[0] = row_tighten<WIDE>(x[0], m, O::bound(m));
 #pragma unroll
-    for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], NTT_TW(a.twA, k * 256 + t), m);
+        for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], tA.template at<256>(k), m);
+    }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) NTT_LDS_ST(P1(k * 256 + t), x[k]);
+    for (int k = 0; k < 16; ++k) NTT_LDS_ST(t + 272 * k, x[k]);                  // P1(k * 256 + t)
     NTT_BARRIER();
     const uint32_t b = t >> 4, i = t & 15;
+    const uint32_t e1 = 272 * b + i;                                            // both padded layouts, spelled out: t < 256
 #pragma unroll
-    for (int j = 0; j < 16; ++j) NTT_LDS_LD(x[j], P1(b * 256 + j * 16 + i));
+    for (int j = 0; j < 16; ++j) NTT_LDS_LD(x[j], e1 + 16 * j);                 // P1(b * 256 + j * 16 + i)
     NTT_BARRIER();
-    reg_ntt<MM, LAZY, 4, false, true, WIDE>(x, a.roots, m);
-    x[0] = row_tighten<WIDE>(x[0], m, O::bound(m));
+    const RowTable<tw_t> tB = row_table(a.twB, 16, 16, i);
+    if constexpr (FUSE && (NTT_ROW_FUSE_TW & 2)) {
+        const RowTable2 tB2 = row_table2(a.twB2, 16, i);
+        fused_pass<MM, LAZY, 16>(x, a.roots, m, tB, tB2);
+    } else {
+        reg_ntt<MM, LAZY, 4, false, true, WIDE>(x, a.roots, m);
+        x[0] = row_tighten<WIDE>(x[0], m, O::bound(m));
 #pragma unroll
-    for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], NTT_TW(a.twB, k * 16 + i), m);
+        for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], tB.template at<16>(k), m);
+    }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) NTT_LDS_ST(P2(b * 256 + k * 16 + i), x[k]);
+    for (int k = 0; k < 16; ++k) NTT_LDS_ST(e1 + 17 * k, x[k]);                 // P2(b * 256 + k * 16 + i)
     NTT_BARRIER();
 #pragma unroll
-    for (int j = 0; j < 16; ++j) NTT_LDS_LD(x[j], P2(t * 16 + j));
+    for (int j = 0; j < 16; ++j) NTT_LDS_LD(x[j], 17 * t + j);                  // P2(t * 16 + j)
     NTT_BARRIER();
     reg_ntt<MM, LAZY, 4, false>(x, a.roots, m);
 }
@@ -78,25 +163,25 @@ __device__ __forceinline__ void row_inverse(uint32_t (&x)[16], uint32_t *lds, co
     using O = Ops<MM, LAZY>;
     reg_ntt<MM, LAZY, 4, false, true, WIDE>(x, a.iroots, m);     // loose values travel through LDS
 #pragma unroll
-    for (int j = 0; j < 16; ++j) NTT_LDS_ST(P2(t * 16 + j), x[j]);
+    for (int j = 0; j < 16; ++j) NTT_LDS_ST(17 * t + j, x[j]);                  // P2(t * 16 + j)
     NTT_BARRIER();
     const uint32_t b = t >> 4, i = t & 15;
+    const uint32_t e1 = 272 * b + i;                                            // both padded layouts, spelled out: t < 256
 #pragma unroll
-    for (int k = 0; k < 16; ++k) NTT_LDS_LD(x[k], P2(b * 256 + k * 16 + i));
+    for (int k = 0; k < 16; ++k) NTT_LDS_LD(x[k], e1 + 17 * k);                 // P2(b * 256 + k * 16 + i)
     NTT_BARRIER();
-    x[0] = row_tighten<WIDE>(x[0], m, O::bound(m));
-#pragma unroll
-    for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], NTT_TW(a.itwB, k * 16 + i), m);
+    using tw_t = typename MM::tw_t;
+    const RowTable<tw_t> tB = row_table(a.itwB, 16, 16, i);
+    twiddle_pass<MM, LAZY, WIDE, 16>(x, m, tB);
     reg_ntt<MM, LAZY, 4, false, true, WIDE>(x, a.iroots, m);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) NTT_LDS_ST(P1(b * 256 + j * 16 + i), x[j]);
+    for (int j = 0; j < 16; ++j) NTT_LDS_ST(e1 + 16 * j, x[j]);                 // P1(b * 256 + j * 16 + i)
     NTT_BARRIER();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) NTT_LDS_LD(x[k], P1(k * 256 + t));
+    for (int k = 0; k < 16; ++k) NTT_LDS_LD(x[k], t + 272 * k);                  // P1(k * 256 + t)
     NTT_BARRIER();
-    x[0] = row_tighten<WIDE>(x[0], m, O::bound(m));
-#pragma unroll
-    for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], NTT_TW(a.itwA, k * 256 + t), m);
+    const RowTable<tw_t> tA = row_table(a.itwA, 16, 256, t);
+    twiddle_pass<MM, LAZY, WIDE, 256>(x, m, tA);
     // loose output: the innermost inverse column level multiplies every row (rows >= 1 by the
     // 4-step twiddle, row 0 by the scale constant), so no reduction is needed here (WIDE: below 8p, any u32 is fine there)
     reg_ntt<MM, LAZY, 4, false, true, WIDE>(x, a.iroots, m);
@@ -126,13 +211,15 @@ __device__ __forceinline__ void row_mul_body(const RowArgs<MM> &a, const ModPara
         xb[4 * q] = vb.x; xb[4 * q + 1] = vb.y; xb[4 * q + 2] = vb.z; xb[4 * q + 3] = vb.w;
     }
 #else
+    const bufrsrc_t ra = make_buf(pa, kRowLen * 4u), rb = make_buf(pb, kRowLen * 4u);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) xa[j] = pa[t + 256 * j];
+    for (int j = 0; j < 16; ++j) xa[j] = buf_load(ra, t * 4u, 1024u * j);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) xb[j] = pb[t + 256 * j];
+    for (int j = 0; j < 16; ++j) xb[j] = buf_load(rb, t * 4u, 1024u * j);
 #endif
-    row_forward<MM, LAZY, WIDE>(xa, lds, t, a, m);
-    row_forward<MM, LAZY, WIDE>(xb, lds, t, a, m);
+    constexpr bool FUSE = NTT_ROW_FUSE_TW && acc4_enabled<MM, WIDE>();
+    row_forward<MM, LAZY, WIDE, FUSE>(xa, lds, t, a, m);
+    row_forward<MM, LAZY, WIDE, FUSE>(xb, lds, t, a, m);
 #pragma unroll
     for (int k = 0; k < 16; ++k) xa[k] = O::mul(xa[k], xb[k], m);
     row_inverse<MM, LAZY, WIDE>(xa, lds, t, a, m);
@@ -147,8 +234,9 @@ __device__ __forceinline__ void row_mul_body(const RowArgs<MM> &a, const ModPara
     for (int q = 0; q < 4; ++q)
         reinterpret_cast<uint4 *>(po + 1024 * q)[t] = make_uint4(xa[4 * q], xa[4 * q + 1], xa[4 * q + 2], xa[4 * q + 3]);
 #else
+    const bufrsrc_t ro = make_buf(po, kRowLen * 4u);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) po[t + 256 * j] = xa[j];
+    for (int j = 0; j < 16; ++j) buf_store(xa[j], ro, t * 4u, 1024u * j);
 #endif
 }
 

@@ -9,7 +9,7 @@ FILES=${@:-kernels_col.hip kernels_col16.hip kernels_row.hip}
 make -j8 >/dev/null
 mkdir -p ../variants build/var_$NAME
 OBJS=""
-for f in kernels_col kernels_col16 kernels_row kernels_fused kernels_misc kernels_crt kernels_u64 engine crt direct64 stream harness; do
+for f in kernels_col kernels_col16 kernels_row kernels_fused kernels_misc kernels_crt kernels_u64 kernels_dist engine crt direct64 stream harness multidev comm; do
   src=$f.hip; [ -f $src ] || src=$f.cpp
   if echo " $FILES " | grep -q " $src "; then
     ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $DEFS -x hip -c $src -o build/var_$NAME/$f.o ) &
@@ -19,5 +19,5 @@ for f in kernels_col kernels_col16 kernels_row kernels_fused kernels_misc kernel
   fi
 done
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OBJS -lhsa-runtime64 -o ../variants/libntt_amd_$NAME.so
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OBJS -lhsa-runtime64 -ldl -o ../variants/libntt_amd_$NAME.so
 ls -la ../variants/libntt_amd_$NAME.so
