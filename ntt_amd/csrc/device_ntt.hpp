@@ -270,7 +270,8 @@ __device__ __forceinline__ void acc4_step(uint32_t (&x)[1 << LOGN], const Roots6
 // tw(k): the plain table entry (Montgomery form in [0, p)) of output k, asked for k = 1, 2, 3, 8 ... 11;
 // t2(q): the pair { centred entry, centred rotated entry } of the q-th output of the difference side, q = 0 ... 7 for
 // k = 4, 5, 6, 7, 12, 13, 14, 15 (engine.cpp: rotated_table).  Outputs in natural order, below `bound` (output 0 tight).
-template <class MM, bool LAZY, class TW, class T2>
+// TW0: output 0 is multiplied as well (by tw(0)).
+template <class MM, bool LAZY, bool TW0 = false, class TW, class T2>
 __device__ __forceinline__ void reg_ntt16_tw(uint32_t (&x)[16], const Roots64<MM> &roots, const ModParams &m,
                                              TW &&tw, T2 &&t2)
 {
@@ -287,7 +288,7 @@ __device__ __forceinline__ void reg_ntt16_tw(uint32_t (&x)[16], const Roots64<MM
         const uint32_t a = x[4 * g], b = x[4 * g + 1], c = x[4 * g + 2], d = x[4 * g + 3];
         const uint32_t s0 = O::add(a, c, m), s1 = O::add(b, d, m);
         const int32_t d0 = (int32_t)(a - c), d1 = (int32_t)(b - d);
-        y[k] = k == 0 ? O::add(s0, s1, m) : O::mul_tw(s0 + s1, tw(k), m);
+        y[k] = (k == 0 && !TW0) ? O::add(s0, s1, m) : O::mul_tw(s0 + s1, tw(k), m);
         y[k + 8] = O::mul_tw_diff(s0, s1, tw(k + 8), m);
         const uint2 ta = t2(k), tb = t2(k + 4);
         const uint32_t y4 = MM::mul2_acc_v(d0, (int32_t)ta.x, d1, (int32_t)ta.y, m);

@@ -224,6 +224,25 @@ static std::vector<uint32_t> rotated_table(uint32_t w, uint32_t cols, uint32_t i
     return t;
 }
 
+// The pair table of the second fused INVERSE pass: its twiddles used to follow the exchange (reader t multiplied its
+// k-th value by w^(k * t)); in front of it, thread (b, i) multiplies its output j by w^(b * (16 j + i)).  Entry
+// (b, q, i) is the pair for the q-th output of the difference side, j = k_q.
+static std::vector<uint32_t> rotated_table_inv(uint32_t w, uint32_t i4, const ModParams &mp)
+{
+    std::vector<uint32_t> t((size_t)16 * 8 * 16 * 2);
+    for (uint32_t b = 0; b < 16; ++b)
+        for (uint32_t q = 0; q < 8; ++q) {
+            const uint32_t k = q < 4 ? q + 4 : q + 8, rot = q < 4 ? i4 : mp.p - i4;
+            for (uint32_t i = 0; i < 16; ++i) {
+                const uint32_t e = h_powmod(w, (uint64_t)b * (16 * k + i), mp.p);
+                const size_t at = 2 * (((size_t)b * 8 + q) * 16 + i);
+                t[at] = (uint32_t)Mont32::center_tw(Mont32::make_tw(e, mp), mp);
+                t[at + 1] = (uint32_t)Mont32::center_tw(Mont32::make_tw(h_mulmod(e, rot, mp.p), mp), mp);
+            }
+        }
+    return t;
+}
+
 template <class MM>
 static std::vector<unsigned char> bytes_of_tw(uint32_t v, const ModParams &mp)
 {
@@ -353,6 +372,11 @@ static int build_tables(ntt_plan *pl)
         rc = upload_table<Mont32>(pl, rotated_table(w4096, 256, i4, mp), &pl->twA2);
         if (rc) return rc;
         rc = upload_table<Mont32>(pl, rotated_table(w256, 16, i4, mp), &pl->twB2);
+        if (rc) return rc;
+        const uint32_t ii4 = h_powmod(iwL, L / 4, p);
+        rc = upload_table<Mont32>(pl, rotated_table(iw256, 16, ii4, mp), &pl->itwB2);
+        if (rc) return rc;
+        rc = upload_table<Mont32>(pl, rotated_table_inv(iw4096, ii4, mp), &pl->itwA2);
     }
     return rc;
 }
@@ -423,6 +447,8 @@ static RowArgs<MM> fill_row(ntt_plan *pl, const uint32_t *a0, const uint32_t *b0
     a.itwB = static_cast<const typename MM::tw_t *>(pl->itwB);
     a.twA2 = static_cast<const uint2 *>(pl->twA2);
     a.twB2 = static_cast<const uint2 *>(pl->twB2);
+    a.itwA2 = static_cast<const uint2 *>(pl->itwA2);
+    a.itwB2 = static_cast<const uint2 *>(pl->itwB2);
     fill_roots<MM>(a.roots, pl->roots);
     fill_roots<MM>(a.iroots, pl->iroots);
     return a;
@@ -1080,10 +1106,15 @@ static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_ki
     pl->lazy = p < (1u << 30);
     if (const char *e = std::getenv("NTT_AMD_FORCE_STRICT"))
         if (e[0] == '1') pl->lazy = false;
-    // 8p <= 2^32: the wide-range transforms (NTT_AMD_WIDE=0 keeps the [0, 2p) kernels; A/B runs and tests of both)
-    pl->wide8 = pl->lazy && p < (1u << 29);
-    if (const char *e = std::getenv("NTT_AMD_WIDE"))
+    // 8p <= 2^32: the wide-range transforms exist, and since the radix-4 steps of the [0, 2p) Montgomery kernels
+    // (device_ntt.hpp: acc4_step, reg_ntt16_tw) they are the slower choice there (p = 469762049: 533 k against 591 k
+    // products/s), so only the Barrett kernels, which have no such steps, take them by default.  NTT_AMD_WIDE=1 / 0
+    // forces / forbids them (A/B runs and the tests of both).
+    pl->wide8 = pl->lazy && p < (1u << 29) && modmul_kind != NTT_MODMUL_MONTGOMERY;
+    if (const char *e = std::getenv("NTT_AMD_WIDE")) {
         if (e[0] == '0') pl->wide8 = false;
+        if (e[0] == '1') pl->wide8 = pl->lazy && p < (1u << 29);
+    }
     // forward column pass: the register kernel wins in a full launch, the LDS-staged one (four times the
     // workgroups, a quarter of the work per thread) when a launch holds a few products only
     // (single product: 9.7 -> 8.2 us, tools/time_single.py).  The Barrett kernels always take the LDS-staged one: their

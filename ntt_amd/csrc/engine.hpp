@@ -188,7 +188,7 @@ struct ntt_plan {
     void *tw_inv[8] = {nullptr};        // innermost level carries the multiply scale (L^-1 [* R])
     void *tw_inv_plain = nullptr;       // innermost level with plain L^-1 (ntt_inverse)
     void *twA = nullptr, *twB = nullptr, *itwA = nullptr, *itwB = nullptr;
-    void *twA2 = nullptr, *twB2 = nullptr;     // Montgomery plans: rotated row tables of the fused forward passes (RowArgs)
+    void *twA2 = nullptr, *twB2 = nullptr, *itwA2 = nullptr, *itwB2 = nullptr;     // Montgomery plans: rotated row tables of the fused forward passes (RowArgs)
     void *small_w = nullptr, *small_iw = nullptr;
     // negacyclic plans (products modulo x^n + 1, L = n): psi^i and psi^-i, psi = g^((p-1)/2n);
     // small_itwist = psi^-i with the multiply scale folded in (L <= 4096 path)

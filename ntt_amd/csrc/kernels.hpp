@@ -58,6 +58,9 @@ struct RowArgs {
     // [8][256] and [8][16] pairs { centred entry, centred rotated entry (times i, resp. -i) } of the q-th such output
     // (engine.cpp: rotated_table).  nullptr otherwise.
     const uint2 *twA2, *twB2;
+    // the same for the inverse passes, whose twiddles move in front of the exchange they used to follow: itwB2 [8][16]
+    // as twB2; itwA2 [16][8][16], entry (b, q, i) = the pair of w^-(b * (16 k_q + i)) (engine.cpp: rotated_table_inv)
+    const uint2 *itwA2, *itwB2;
 };
 
 // A whole product of transform length L = 4096 in the row kernel (no column level): zero padding

@@ -20,7 +20,7 @@
 #endif
 
 #ifndef NTT_ROW_FUSE_TW
-#define NTT_ROW_FUSE_TW 3                // bit 0: first pass ([16][256] table), bit 1: second pass ([16][16] table)
+#define NTT_ROW_FUSE_TW 7                // bit 0: first forward pass ([16][256] table), bit 1: second ([16][16] table), bit 2: the inverse's
 #endif
 
 namespace ntt {
@@ -37,7 +37,7 @@ template <class TW>
 struct RowTable {
     bufrsrc_t r;
     uint32_t lane;                                    // byte offset of this lane's column
-    template <int COLS>
+    template <int COLS>                               // entry k of this lane: COLS entries further per k
     __device__ __forceinline__ TW at(int k) const
     {
 #if defined(NTT_ABL_NOTW)
@@ -63,9 +63,9 @@ struct RowTable2 {
         return make_uint2(v[0], v[1]);
     }
 };
-__device__ __forceinline__ RowTable2 row_table2(const uint2 *base, uint32_t cols, uint32_t col)
+__device__ __forceinline__ RowTable2 row_table2(const uint2 *base, uint32_t cols, uint32_t col, uint32_t rows = 8)
 {
-    return RowTable2{make_buf(base, 8u * cols * 8u), col * 8u};
+    return RowTable2{make_buf(base, rows * cols * 8u), col * 8u};
 }
 
 // WIDE (p < 2^29, device_ntt.hpp): the loose 16-point transforms keep sums unreduced up to 4p and hand out values below
@@ -79,19 +79,20 @@ __device__ __forceinline__ uint32_t row_tighten(uint32_t x, const ModParams &m, 
 // One fused pass: the table entries are requested first, as one batch in front of the arithmetic (the scheduling barrier
 // keeps them there: left alone, the compiler issued every table load of the kernel directly in front of its use, each
 // with a full wait -- 530 k instead of 570 k products/s).
-template <class MM, bool LAZY, int COLS>
+// COLS / COLS2: entries between consecutive outputs in the plain and in the pair table; TW0: output 0 has a twiddle too
+template <class MM, bool LAZY, int COLS, int COLS2 = COLS, bool TW0 = false>
 __device__ __forceinline__ void fused_pass(uint32_t (&x)[16], const Roots64<MM> &roots, const ModParams &m,
                                            const RowTable<typename MM::tw_t> &tab, const RowTable2 &tab2)
 {
     typename MM::tw_t tv[16];
     uint2 t2[8];
 #pragma unroll
-    for (int k = 1; k < 16; ++k)
+    for (int k = TW0 ? 0 : 1; k < 16; ++k)
         if ((k & 4) == 0) tv[k] = tab.template at<COLS>(k);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) t2[q] = tab2.at<COLS>(q);
+    for (int q = 0; q < 8; ++q) t2[q] = tab2.at<COLS2>(q);
     __builtin_amdgcn_sched_barrier(0);
-    reg_ntt16_tw<MM, LAZY>(x, roots, m, [&](int k) { return tv[k]; }, [&](int q) { return t2[q]; });
+    reg_ntt16_tw<MM, LAZY, TW0>(x, roots, m, [&](int k) { return tv[k]; }, [&](int q) { return t2[q]; });
 }
 
 // x[k] *= table entry k (k >= 1; x[0] is only brought into range), the entries requested as one batch
@@ -103,6 +104,22 @@ __device__ __forceinline__ void twiddle_pass(uint32_t (&x)[16], const ModParams 
 #pragma unroll
     for (int k = 1; k < 16; ++k) tv[k] = tab.template at<COLS>(k);
     __builtin_amdgcn_sched_barrier(0);
+    x[0] = row_tighten<WIDE>(x[0], m, O::bound(m));
+#pragma unroll
+    for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], tv[k], m);
+}
+
+// a forward pass that is not fused: transform (loose outputs), then the twiddles, their entries requested in front of it
+template <class MM, bool LAZY, bool WIDE, int COLS>
+__device__ __forceinline__ void plain_pass(uint32_t (&x)[16], const Roots64<MM> &roots, const ModParams &m,
+                                           const RowTable<typename MM::tw_t> &tab)
+{
+    using O = Ops<MM, LAZY>;
+    typename MM::tw_t tv[16];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) tv[k] = tab.template at<COLS>(k);
+    __builtin_amdgcn_sched_barrier(0);
+    reg_ntt<MM, LAZY, 4, false, true, WIDE>(x, roots, m);          // loose: 15 of 16 outputs are multiplied next
     x[0] = row_tighten<WIDE>(x[0], m, O::bound(m));
 #pragma unroll
     for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], tv[k], m);
@@ -123,10 +140,7 @@ __device__ __forceinline__ void row_forward(uint32_t (&x)[16], uint32_t *lds, co
         const RowTable2 tA2 = row_table2(a.twA2, 256, t);
         fused_pass<MM, LAZY, 256>(x, a.roots, m, tA, tA2);
     } else {
-        reg_ntt<MM, LAZY, 4, false, true, WIDE>(x, a.roots, m);      // loose: 15 of 16 outputs are multiplied next
-        x[0] = row_tighten<WIDE>(x[0], m, O::bound(m));
-#pragma unroll
-        for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], tA.template at<256>(k), m);
+        plain_pass<MM, LAZY, WIDE, 256>(x, a.roots, m, tA);
     }
 #pragma unroll
     for (int k = 0; k < 16; ++k) NTT_LDS_ST(t + 272 * k, x[k]);                  // P1(k * 256 + t)
@@ -141,10 +155,7 @@ __device__ __forceinline__ void row_forward(uint32_t (&x)[16], uint32_t *lds, co
         const RowTable2 tB2 = row_table2(a.twB2, 16, i);
         fused_pass<MM, LAZY, 16>(x, a.roots, m, tB, tB2);
     } else {
-        reg_ntt<MM, LAZY, 4, false, true, WIDE>(x, a.roots, m);
-        x[0] = row_tighten<WIDE>(x[0], m, O::bound(m));
-#pragma unroll
-        for (int k = 1; k < 16; ++k) x[k] = O::mul_tw(x[k], tB.template at<16>(k), m);
+        plain_pass<MM, LAZY, WIDE, 16>(x, a.roots, m, tB);
     }
 #pragma unroll
     for (int k = 0; k < 16; ++k) NTT_LDS_ST(e1 + 17 * k, x[k]);                 // P2(b * 256 + k * 16 + i)
@@ -156,11 +167,39 @@ __device__ __forceinline__ void row_forward(uint32_t (&x)[16], uint32_t *lds, co
 }
 
 // x[k] = spectrum at position 16*t + k on entry; on exit x[j] = row[t + 256*j] (unscaled).
-template <class MM, bool LAZY, bool WIDE = false>
+// FUSE: the twiddles of the second and third pass are applied by the thread that PRODUCES the value, fused into the
+// pass in front of the exchange (row k of a table becomes a per-thread row; the tables are symmetric, w^(k * i)).
+template <class MM, bool LAZY, bool WIDE = false, bool FUSE = false>
 __device__ __forceinline__ void row_inverse(uint32_t (&x)[16], uint32_t *lds, const uint32_t t,
                                             const RowArgs<MM> &a, const ModParams &m)
 {
     using O = Ops<MM, LAZY>;
+    if constexpr (FUSE) {
+        using tw_t = typename MM::tw_t;
+        const uint32_t b = t >> 4, i = t & 15;
+        const uint32_t e1 = 272 * b + i;
+        // the reader (b', i') of exchange 2 multiplied its k-th value by itwB[k][i']; that value is output j = i' of thread
+        // 16 b' + k: entry [t & 15][j] = [j][t & 15]
+        fused_pass<MM, LAZY, 16>(x, a.iroots, m, row_table(a.itwB, 16, 16, i), row_table2(a.itwB2, 16, i));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) NTT_LDS_ST(17 * t + j, x[j]);
+        NTT_BARRIER();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) NTT_LDS_LD(x[k], e1 + 17 * k);
+        NTT_BARRIER();
+        // the reader t' of exchange 1 multiplied its k-th value by itwA[k][t']; that value is output j of thread (b, i) with
+        // k = b, t' = 16 j + i: entry [b][16 j + i], and output 0 has a twiddle as well
+        fused_pass<MM, LAZY, 16, 16, true>(x, a.iroots, m, row_table(a.itwA, 16, 256, b * 256 + i),
+                                           row_table2(a.itwA2, 16, b * 128 + i, 128));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) NTT_LDS_ST(e1 + 16 * j, x[j]);
+        NTT_BARRIER();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) NTT_LDS_LD(x[k], t + 272 * k);
+        NTT_BARRIER();
+        reg_ntt<MM, LAZY, 4, false, true, WIDE>(x, a.iroots, m);
+        return;
+    }
     reg_ntt<MM, LAZY, 4, false, true, WIDE>(x, a.iroots, m);     // loose values travel through LDS
 #pragma unroll
     for (int j = 0; j < 16; ++j) NTT_LDS_ST(17 * t + j, x[j]);                  // P2(t * 16 + j)
@@ -222,7 +261,7 @@ __device__ __forceinline__ void row_mul_body(const RowArgs<MM> &a, const ModPara
     row_forward<MM, LAZY, WIDE, FUSE>(xb, lds, t, a, m);
 #pragma unroll
     for (int k = 0; k < 16; ++k) xa[k] = O::mul(xa[k], xb[k], m);
-    row_inverse<MM, LAZY, WIDE>(xa, lds, t, a, m);
+    row_inverse<MM, LAZY, WIDE, FUSE && (NTT_ROW_FUSE_TW & 4)>(xa, lds, t, a, m);
     uint32_t *__restrict__ po = a.out + row;
 #if defined(NTT_ABL_NODATA)
     uint32_t acc = 0;
