@@ -50,6 +50,12 @@ struct Ops {
         uint32_t r = MM::mul_tw_diff(u, v, w, bound(m), m);
         return LAZY ? r : csub(r, m.p);
     }
+    // the same for a wave-uniform twiddle (Mont32::mul_tw_diff_s)
+    static __device__ __forceinline__ uint32_t mul_tw_diff_s(uint32_t u, uint32_t v, tw_t w, const ModParams &m)
+    {
+        uint32_t r = MM::mul_tw_diff_s(u, v, w, bound(m), m);
+        return LAZY ? r : csub(r, m.p);
+    }
     static __device__ __forceinline__ uint32_t canon(uint32_t x, const ModParams &m)
     {
         return LAZY ? csub(x, m.p) : x;
@@ -250,7 +256,7 @@ __device__ __forceinline__ void acc4_step(uint32_t (&x)[1 << LOGN], const Roots6
 #else
             const uint32_t s0 = O::add(a, c, m), s1 = O::add(b, d, m);
             x[ia] = O::add(s0, s1, m);
-            x[ib] = j == 0 ? O::sub(s0, s1, m) : O::mul_tw_diff(s0, s1, roots.w[2 * j * step], m);
+            x[ib] = j == 0 ? O::sub(s0, s1, m) : O::mul_tw_diff_s(s0, s1, roots.w[2 * j * step], m);
 #endif
             const uint32_t y2 = MM::mul2_acc(d0, W(j * step), d1, W((j + hq) * step), m);
             const uint32_t y3 = MM::mul2_acc(d0, W(3 * j * step), d1, W((3 * j + hq) * step + 32), m);
@@ -369,7 +375,7 @@ __device__ __forceinline__ void reg_ntt(uint32_t (&x)[1 << LOGN], const Roots64<
                 } else {
                     x[blk + j] = O::add(u, v, m);
                     if (j == 0) x[blk + j + half] = O::sub(u, v, m);
-                    else x[blk + j + half] = O::mul_tw_diff(u, v, roots.w[j * step], m);   // signed-mad form
+                    else x[blk + j + half] = O::mul_tw_diff_s(u, v, roots.w[j * step], m); // signed-mad form
                 }
             }
         }

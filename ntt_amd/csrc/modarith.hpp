@@ -223,6 +223,21 @@ struct Mont32 {
     {
         return w > (m.p >> 1) ? (int32_t)(w - m.p) : (int32_t)w;
     }
+    // mul_tw_diff for a WAVE-UNIFORM twiddle (the w_64 powers of the register transforms): the twiddle is the scalar
+    // operand and the addend a vector pair, so no v_mov copies the twiddle into a vector register first (a VOP3 takes one
+    // scalar source; the forward column kernel spent 80 of its 1420 instructions per column on such copies)
+    static NTT_HD uint32_t mul_tw_diff_s(uint32_t u, uint32_t v, tw_t w, uint32_t bound, const ModParams &m)
+    {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTT_NO_MADI64)
+        (void)bound;
+        const uint64_t C = (uint64_t)m.p << 31;
+        uint64_t T, carry;
+        asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(T), "=s"(carry) : "v"(u - v), "s"(w), "v"(C));
+        return redc_lazy(T, m);
+#else
+        return mul_tw(u - v + bound, w, m);
+#endif
+    }
     // a*b*R^-1 mod p in [0, 2p); a any u32, b < p (or a*b < 2^32 * p)
     static NTT_HD uint32_t mul_raw(uint32_t a, uint32_t b, const ModParams &m)
     {
@@ -257,6 +272,10 @@ struct Barrett32 {
     static NTT_HD uint32_t mul_tw_diff(uint32_t u, uint32_t v, tw_t t, uint32_t bound, const ModParams &m)
     {
         return mul_tw(u - v + bound, t, m);            // the quotient estimate needs the non-negative value
+    }
+    static NTT_HD uint32_t mul_tw_diff_s(uint32_t u, uint32_t v, tw_t t, uint32_t bound, const ModParams &m)
+    {
+        return mul_tw_diff(u, v, t, bound, m);
     }
     // Classic Barrett (HAC 14.42, base 2) for T = a*b with a, b < p < 2^k:
     // q = ((T >> (k-1)) * mu) >> (k+1) underestimates floor(T/p) by at most 2, so
