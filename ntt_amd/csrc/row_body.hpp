@@ -1,6 +1,7 @@
 // row_body.hpp -- device bodies of the 4096-point row transforms (see kernels_row.hip), shared by
 // the stand-alone kernels and the one-kernel products (kernels_fused.hip).
 #pragma once
+#include <cstring>
 #include "device_ntt.hpp"
 
 // Ablation switches for timing experiments (tools/ablate_row.sh); never defined in the shipped build:
@@ -41,7 +42,9 @@ struct RowTable {
     __device__ __forceinline__ TW at(int k) const
     {
 #if defined(NTT_ABL_NOTW)
-        return TW{};
+        TW w{};
+        std::memcpy(&w, &lane, sizeof(lane));
+        return w;
 #else
         return buf_load_tw<TW>(r, lane, (uint32_t)k * COLS * (uint32_t)sizeof(TW));
 #endif
@@ -59,8 +62,12 @@ struct RowTable2 {
     template <int COLS>
     __device__ __forceinline__ uint2 at(int q) const
     {
+#if defined(NTT_ABL_NOTW)
+        return make_uint2(lane, 3u * lane);
+#else
         const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane, (int)((uint32_t)q * COLS * 8u), 0);
         return make_uint2(v[0], v[1]);
+#endif
     }
 };
 __device__ __forceinline__ RowTable2 row_table2(const uint2 *base, uint32_t cols, uint32_t col, uint32_t rows = 8)
