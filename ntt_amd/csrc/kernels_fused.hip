@@ -39,11 +39,11 @@ __device__ __forceinline__ void fused_row(uint32_t (&xa)[16], uint32_t (&xb)[16]
                                           const RowArgs<MM> &row, const ModParams &m)
 {
     using O = Ops<MM, LAZY>;
-    row_forward<MM, LAZY>(xa, lds, t, row, m);
-    row_forward<MM, LAZY>(xb, lds, t, row, m);
+    row_forward<MM, LAZY, false, row_fuse<MM, false>()>(xa, lds, t, row, m);
+    row_forward<MM, LAZY, false, row_fuse<MM, false>()>(xb, lds, t, row, m);
 #pragma unroll
     for (int k = 0; k < 16; ++k) xa[k] = O::mul(xa[k], xb[k], m);
-    row_inverse<MM, LAZY>(xa, lds, t, row, m);
+    row_inverse<MM, LAZY, false, row_fuse_inv<MM, false>()>(xa, lds, t, row, m);
 }
 
 // one row of seq_product_kernel: recompute the forward column level, transform, multiply, inverse, inverse twiddle, park

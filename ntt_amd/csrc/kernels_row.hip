@@ -51,11 +51,11 @@ __global__ void __launch_bounds__(256) row_product_kernel(const Row4096Args<MM> 
             xb[j] = O::mul_tw(xb[j], w, m);
         }
     }
-    row_forward<MM, LAZY, WIDE>(xa, lds, t, a.row, m);
-    row_forward<MM, LAZY, WIDE>(xb, lds, t, a.row, m);
+    row_forward<MM, LAZY, WIDE, row_fuse<MM, WIDE>()>(xa, lds, t, a.row, m);
+    row_forward<MM, LAZY, WIDE, row_fuse<MM, WIDE>()>(xb, lds, t, a.row, m);
 #pragma unroll
     for (int k = 0; k < 16; ++k) xa[k] = O::mul(xa[k], xb[k], m);
-    row_inverse<MM, LAZY, WIDE>(xa, lds, t, a.row, m);        // loose outputs, unscaled
+    row_inverse<MM, LAZY, WIDE, row_fuse_inv<MM, WIDE>()>(xa, lds, t, a.row, m);        // loose outputs, unscaled
     uint32_t *__restrict__ po = a.row.out + (size_t)blockIdx.x * a.out_stride;
     if (a.fold) {                                             // x^2048 + 1: position i + 2048 sits in the same thread (uniform)
 #pragma unroll
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) row_fwd_kernel(const RowArgs<MM> a, const
     uint32_t x[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) x[j] = pa[t + 256 * j];
-    row_forward<MM, LAZY, WIDE>(x, lds, t, a, m);
+    row_forward<MM, LAZY, WIDE, row_fuse<MM, WIDE>()>(x, lds, t, a, m);
     uint4 *__restrict__ po = reinterpret_cast<uint4 *>(a.out + row + 16 * t);
 #pragma unroll
     for (int q = 0; q < 4; ++q) po[q] = make_uint4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) row_inv_kernel(const RowArgs<MM> a, const
         const uint4 v = pa[q];
         x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
     }
-    row_inverse<MM, LAZY, WIDE>(x, lds, t, a, m);
+    row_inverse<MM, LAZY, WIDE, row_fuse_inv<MM, WIDE>()>(x, lds, t, a, m);
     uint32_t *__restrict__ po = a.out + row;
 #pragma unroll
     for (int j = 0; j < 16; ++j) po[t + 256 * j] = x[j];

@@ -83,6 +83,12 @@ __device__ __forceinline__ uint32_t row_tighten(uint32_t x, const ModParams &m, 
     return WIDE ? tighten_wide(x, m) : csub(x, bound);
 }
 
+// which row transforms run the fused passes (Montgomery plans outside the wide range; RowArgs then carries the pair tables)
+template <class MM, bool WIDE>
+constexpr bool row_fuse() { return NTT_ROW_FUSE_TW && acc4_enabled<MM, WIDE>(); }
+template <class MM, bool WIDE>
+constexpr bool row_fuse_inv() { return (NTT_ROW_FUSE_TW & 4) && acc4_enabled<MM, WIDE>(); }
+
 // One fused pass: the table entries are requested first, as one batch in front of the arithmetic (the scheduling barrier
 // keeps them there: left alone, the compiler issued every table load of the kernel directly in front of its use, each
 // with a full wait -- 530 k instead of 570 k products/s).
@@ -263,12 +269,12 @@ __device__ __forceinline__ void row_mul_body(const RowArgs<MM> &a, const ModPara
 #pragma unroll
     for (int j = 0; j < 16; ++j) xb[j] = buf_load(rb, t * 4u, 1024u * j);
 #endif
-    constexpr bool FUSE = NTT_ROW_FUSE_TW && acc4_enabled<MM, WIDE>();
+    constexpr bool FUSE = row_fuse<MM, WIDE>();
     row_forward<MM, LAZY, WIDE, FUSE>(xa, lds, t, a, m);
     row_forward<MM, LAZY, WIDE, FUSE>(xb, lds, t, a, m);
 #pragma unroll
     for (int k = 0; k < 16; ++k) xa[k] = O::mul(xa[k], xb[k], m);
-    row_inverse<MM, LAZY, WIDE, FUSE && (NTT_ROW_FUSE_TW & 4)>(xa, lds, t, a, m);
+    row_inverse<MM, LAZY, WIDE, row_fuse_inv<MM, WIDE>()>(xa, lds, t, a, m);
     uint32_t *__restrict__ po = a.out + row;
 #if defined(NTT_ABL_NODATA)
     uint32_t acc = 0;
