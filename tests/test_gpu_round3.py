@@ -488,3 +488,44 @@ def test_small_calls_on_pageable_arrays(nt, monkeypatch):
     ib = rng.integers(0, p, size=70000, dtype=np.int64).astype(np.int32)
     assert np.array_equal(nt.poly_multiply(ia, ib, p).view(np.uint32), orc.poly_multiply(ia.view(np.uint32), ib.view(np.uint32), p))
     ctx.close()
+
+
+@pytest.mark.parametrize("limit,n,batch", [(1 << 30, 1500, 5), (1 << 30, 40000, 3), (1 << 30, 131072, 50),
+                                           (1 << 31, 1500, 5), (1 << 31, 40000, 3), (1 << 31, 131072, 50)])
+def test_two_products_per_reduction_at_the_range_ends(nt, ctx, limit, n, batch):
+    """The radix-4 steps and fused passes of the Montgomery kernels add two signed products d0 w0 + d1 w1 before ONE
+    reduction (modarith.hpp: mul2_acc; device_ntt.hpp: acc4_step, reg_ntt16_tw): the bound 2 * 2p * p / 2 <= p * 2^31 is
+    tightest for the largest lazy prime (below 2^30) and the largest strict one (below 2^31).  Largest primes of both
+    ranges with 2^18 | p - 1, rows of all p - 1, of alternating 0 / p - 1 (the largest differences) and random rows; the
+    one-kernel product (L = 4096), a 32-point and a 64-point column level.  No oracle reaches these primes with its fixed
+    generator 3: evaluation identities on every row plus an exact schoolbook check of the short product."""
+    import torch
+    from test_gpu_full_configs import _check_rows
+    p = _largest_prime_below(limit, 18)
+    assert p > limit - (1 << 26)
+    rng = np.random.default_rng(n + batch + (limit >> 20))
+    a = rng.integers(0, p, size=(batch, n), dtype=np.int64).astype(np.uint32)
+    b = rng.integers(0, p, size=(batch, n), dtype=np.int64).astype(np.uint32)
+    a[0, :] = p - 1
+    b[0, :] = p - 1
+    a[1, ::2], a[1, 1::2] = p - 1, 0
+    b[1, ::2], b[1, 1::2] = 0, p - 1
+    a[2, :] = p - 1
+    b[2, :] = 1
+    da, db = torch.from_numpy(a.view(np.int32)).cuda(), torch.from_numpy(b.view(np.int32)).cuda()
+    plan = ctx.plan(p, n, batch, nt.MONTGOMERY)
+    out = torch.full((batch, 2 * n - 1), -1, dtype=torch.int32, device="cuda")
+    plan.multiply(da, db, out=out, batch=batch)
+    ctx.synchronize()
+    plan.close()
+    _check_rows(da, db, out, 2 * n - 1, p, torch, rng)
+    got = out.cpu().numpy().view(np.uint32)
+    # row 0 in closed form: (p - 1)^2 = 1, so coefficient k of the product is min(k, 2n - 2 - k) + 1
+    k = np.arange(2 * n - 1, dtype=np.int64)
+    assert np.array_equal(got[0].astype(np.int64), (np.minimum(k, 2 * n - 2 - k) + 1) % p)
+    # row 2: all p - 1 times all ones: coefficient k is -(min(k, 2n - 2 - k) + 1) mod p
+    assert np.array_equal(got[2].astype(np.int64), (-(np.minimum(k, 2 * n - 2 - k) + 1)) % p)
+    # exact schoolbook for the first 64 coefficients of two random rows (big-integer arithmetic)
+    for r in (batch - 2, batch - 1):
+        ar, br = [int(v) for v in a[r][:64]], [int(v) for v in b[r][:64]]
+        assert [int(v) for v in got[r][:64]] == [sum(ar[i] * br[kk - i] for i in range(kk + 1)) % p for kk in range(64)]
