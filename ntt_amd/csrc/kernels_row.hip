@@ -19,8 +19,13 @@
 
 namespace ntt {
 
+#if defined(NTT_ROW_WAVES)                         // experiment builds: cap the registers for this many waves per SIMD
+#define NTT_ROW_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(NTT_ROW_WAVES, NTT_ROW_WAVES)))
+#else
+#define NTT_ROW_WAVES_ATTR
+#endif
 template <class MM, bool LAZY, bool WIDE = false>
-__global__ void __launch_bounds__(256) row_mul_kernel(const RowArgs<MM> a, const ModParams m)
+__global__ void __launch_bounds__(256) NTT_ROW_WAVES_ATTR row_mul_kernel(const RowArgs<MM> a, const ModParams m)
 {
     __shared__ uint32_t lds[kLdsWords];
     row_mul_body<MM, LAZY, WIDE>(a, m, lds, blockIdx.x);

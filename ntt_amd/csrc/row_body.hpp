@@ -20,6 +20,9 @@
 #define NTT_BARRIER() __syncthreads()
 #endif
 
+#ifndef NTT_ROW_SHARE_TW
+#define NTT_ROW_SHARE_TW 1
+#endif
 #ifndef NTT_ROW_FUSE_TW
 #define NTT_ROW_FUSE_TW 7                // bit 0: first forward pass ([16][256] table), bit 1: second ([16][16] table), bit 2: the inverse's
 #endif
@@ -179,6 +182,57 @@ __device__ __forceinline__ void row_forward(uint32_t (&x)[16], uint32_t *lds, co
     reg_ntt<MM, LAZY, 4, false>(x, a.roots, m);
 }
 
+// Both operands' forward transforms side by side (fused passes only): one read of every table entry serves both, so a
+// workgroup reads 46 KiB less from its tables per row (a third of its table reads; each operand's exchange still has
+// the tile to itself).
+template <class MM, bool LAZY, int COLS>
+__device__ __forceinline__ void fused_pass2(uint32_t (&xa)[16], uint32_t (&xb)[16], const Roots64<MM> &roots, const ModParams &m,
+                                            const RowTable<typename MM::tw_t> &tab, const RowTable2 &tab2)
+{
+    typename MM::tw_t tv[16];
+    uint2 t2[8];
+#pragma unroll
+    for (int k = 1; k < 16; ++k)
+        if ((k & 4) == 0) tv[k] = tab.template at<COLS>(k);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t2[q] = tab2.at<COLS>(q);
+    __builtin_amdgcn_sched_barrier(0);
+    reg_ntt16_tw<MM, LAZY>(xa, roots, m, [&](int k) { return tv[k]; }, [&](int q) { return t2[q]; });
+    reg_ntt16_tw<MM, LAZY>(xb, roots, m, [&](int k) { return tv[k]; }, [&](int q) { return t2[q]; });
+}
+template <class MM, bool LAZY>
+__device__ __forceinline__ void row_forward2(uint32_t (&xa)[16], uint32_t (&xb)[16], uint32_t *lds, const uint32_t t,
+                                             const RowArgs<MM> &a, const ModParams &m)
+{
+    using tw_t = typename MM::tw_t;
+    const uint32_t b = t >> 4, i = t & 15;
+    const uint32_t e1 = 272 * b + i;
+    fused_pass2<MM, LAZY, 256>(xa, xb, a.roots, m, row_table(a.twA, 16, 256, t), row_table2(a.twA2, 256, t));
+    auto exchange1 = [&](uint32_t (&x)[16]) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) NTT_LDS_ST(t + 272 * k, x[k]);
+        NTT_BARRIER();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) NTT_LDS_LD(x[j], e1 + 16 * j);
+        NTT_BARRIER();
+    };
+    exchange1(xa);
+    exchange1(xb);
+    fused_pass2<MM, LAZY, 16>(xa, xb, a.roots, m, row_table(a.twB, 16, 16, i), row_table2(a.twB2, 16, i));
+    auto exchange2 = [&](uint32_t (&x)[16]) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) NTT_LDS_ST(e1 + 17 * k, x[k]);
+        NTT_BARRIER();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) NTT_LDS_LD(x[j], 17 * t + j);
+        NTT_BARRIER();
+    };
+    exchange2(xa);
+    exchange2(xb);
+    reg_ntt<MM, LAZY, 4, false>(xa, a.roots, m);
+    reg_ntt<MM, LAZY, 4, false>(xb, a.roots, m);
+}
+
 // x[k] = spectrum at position 16*t + k on entry; on exit x[j] = row[t + 256*j] (unscaled).
 // FUSE: the twiddles of the second and third pass are applied by the thread that PRODUCES the value, fused into the
 // pass in front of the exchange (row k of a table becomes a per-thread row; the tables are symmetric, w^(k * i)).
@@ -270,8 +324,12 @@ __device__ __forceinline__ void row_mul_body(const RowArgs<MM> &a, const ModPara
     for (int j = 0; j < 16; ++j) xb[j] = buf_load(rb, t * 4u, 1024u * j);
 #endif
     constexpr bool FUSE = row_fuse<MM, WIDE>();
-    row_forward<MM, LAZY, WIDE, FUSE>(xa, lds, t, a, m);
-    row_forward<MM, LAZY, WIDE, FUSE>(xb, lds, t, a, m);
+    if constexpr (FUSE && NTT_ROW_SHARE_TW && (NTT_ROW_FUSE_TW & 3) == 3) {
+        row_forward2<MM, LAZY>(xa, xb, lds, t, a, m);
+    } else {
+        row_forward<MM, LAZY, WIDE, FUSE>(xa, lds, t, a, m);
+        row_forward<MM, LAZY, WIDE, FUSE>(xb, lds, t, a, m);
+    }
 #pragma unroll
     for (int k = 0; k < 16; ++k) xa[k] = O::mul(xa[k], xb[k], m);
     row_inverse<MM, LAZY, WIDE, row_fuse_inv<MM, WIDE>()>(xa, lds, t, a, m);
