@@ -24,7 +24,7 @@
 #define NTT_ROW_SHARE_TW 1
 #endif
 #ifndef NTT_ROW_FUSE_TW
-#define NTT_ROW_FUSE_TW 7                // bit 0: first forward pass ([16][256] table), bit 1: second ([16][16] table), bit 2: the inverse's
+#define NTT_ROW_FUSE_TW 15               // bits 0 / 1: first / second forward pass, 2: the inverse's first, 3: its second (A/B builds)
 #endif
 
 namespace ntt {
@@ -256,8 +256,19 @@ __device__ __forceinline__ void row_inverse(uint32_t (&x)[16], uint32_t *lds, co
         NTT_BARRIER();
         // the reader t' of exchange 1 multiplied its k-th value by itwA[k][t']; that value is output j of thread (b, i) with
         // k = b, t' = 16 j + i: entry [b][16 j + i], and output 0 has a twiddle as well
-        fused_pass<MM, LAZY, 16, 16, true>(x, a.iroots, m, row_table(a.itwA, 16, 256, b * 256 + i),
-                                           row_table2(a.itwA2, 16, b * 128 + i, 128));
+        if constexpr ((NTT_ROW_FUSE_TW & 8) != 0) {
+            fused_pass<MM, LAZY, 16, 16, true>(x, a.iroots, m, row_table(a.itwA, 16, 256, b * 256 + i),
+                                               row_table2(a.itwA2, 16, b * 128 + i, 128));
+        } else {                                                // the same twiddles, not fused (9 table words per lane less)
+            const RowTable<tw_t> tA = row_table(a.itwA, 16, 256, b * 256 + i);
+            tw_t tv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tv[k] = tA.template at<16>(k);
+            __builtin_amdgcn_sched_barrier(0);
+            reg_ntt<MM, LAZY, 4, false, true, WIDE>(x, a.iroots, m);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x[k] = O::mul_tw(x[k], tv[k], m);
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) NTT_LDS_ST(e1 + 16 * j, x[j]);
         NTT_BARRIER();
