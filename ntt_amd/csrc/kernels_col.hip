@@ -46,9 +46,12 @@ __device__ __forceinline__ void col_body(const ColArgs<MM> &a, const ModParams &
             // the caller's u64 coefficient (beyond in_len: 0), reduced modulo p on the way in: hi * 2^32 + lo
             const bufrsrc_t rin64 = make_buf(reinterpret_cast<const uint64_t *>(a.in[op]) + (size_t)by * a.in_stride, a.in_len * 8u);
             const auto v = __builtin_amdgcn_raw_buffer_load_b64(rin64, (int)(2u * (voff + ((uint32_t)i1 << rowsh))), 0, NTT_NT_AUX);
-            const uint32_t h = csub(Barrett32::mul_tw(v[1], a.in_two32, m), m.p);
-            const uint32_t l = csub(Barrett32::mul_tw(v[0], a.in_one, m), m.p);
-            x[i1] = csub(h + l, m.p);
+            // hi * 2^32 + lo = REDC(hi * R^2 + lo * R): two multiply-adds into one accumulator and one reduction (6
+            // instructions; two Shoup products, their reductions and a modular add took 13).  The sum is below 2^33 p and
+            // with the reduction's q p below 3 * 2^32 p < 2^64 for p < 2^32 / 3 (launch_col_u64in checks it: every CRT
+            // prime is), the result below 3p
+            const uint32_t r = Mont32::redc_lazy((uint64_t)v[1] * m.r2 + (uint64_t)v[0] * m.r1, m);
+            x[i1] = LAZY ? csub(r, m.p2) : csub(csub(r, m.p2), m.p);
         } else x[i1] = (!INVERSE && HALF) ? buf_load_nt(rin, voff + ((uint32_t)i1 << rowsh), 0)     // the caller's operand
                                           : buf_load(rin, voff + ((uint32_t)i1 << rowsh), 0);
     }
@@ -217,6 +220,7 @@ static unsigned walk_cap()
 bool launch_col_u64in(bool lazy, int logN1, const void *args, const ModParams &mp, unsigned cols_per_row, unsigned batch,
                       unsigned nops, hipStream_t s)
 {
+    if (mp.p >= 0x55555555u) return false;                // the input reduction of col_body needs 3 * 2^32 p < 2^64
     dim3 grid(cols_per_row / 256, batch, nops);
     auto a = *static_cast<const ColArgs<Mont32> *>(args);
     const unsigned cap = walk_cap();
