@@ -1152,10 +1152,12 @@ static int plan_create(ntt_ctx *ctx, uint32_t p, int n, int batch, int modmul_ki
         // Measured (profiles/sweep_chunk_r01.txt, profiles/sweep_chunk_r01d.txt): throughput rises
         // with the chunk up to ~40 products (fewer launches, smaller tail rounds), is flat from 40
         // to 56 and drops 5 % at 64 and beyond, where the intermediates of the two lanes no longer
-        // fit the 256 MiB Infinity Cache together: the default is 96 MiB per lane (48 products at
-        // L = 2^18).
+        // fit the 256 MiB Infinity Cache together: the default was 96 MiB per lane (48 products at
+        // L = 2^18).  With the shorter kernels of round 3 the launches count for more: 56 products +0.65 %, 64
+        // +0.85 %, 72 and more -9 % (profiles/sweep_chunk_r03h.txt, sweep_chunk_r03k.txt): 112 MiB per lane (56 products),
+        // one step away from the edge.
         size_t per = (size_t)L * sizeof(uint32_t);
-        long chunk = (long)((96u << 20) / (2 * per));
+        long chunk = (long)((112u << 20) / (2 * per));
         if (const char *e = std::getenv("NTT_AMD_CHUNK")) chunk = std::atol(e);
         const bool chunk_forced = std::getenv("NTT_AMD_CHUNK") != nullptr;
         chunk = std::max<long>(1, std::min<long>(chunk, batch));

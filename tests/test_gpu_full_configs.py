@@ -67,9 +67,10 @@ def test_config1_batch_1024():
     ctx.synchronize()
     assert int((ab[:, 2 * n - 1:] != -1).sum()) == 0              # entries >= 2n-1 of a row stay untouched
     _check_rows(a, b, ab, 2 * n - 1, p, torch, np.random.default_rng(1))
-    # launch groups are 48 products (21 full ones and one of 16, alternating between the two stream lanes): rows on
-    # both sides of the first lane-0 | lane-1 and lane-1 | lane-0 boundaries and the last product, against the oracle
-    rows = (0, 47, 48, 95, 96, B - 1)
+    # launch groups are 56 products (18 full ones and one of 16, alternating between the two stream lanes; 48 until the
+    # end of round 3): rows on both sides of the first lane-0 | lane-1 and lane-1 | lane-0 boundaries of either
+    # grouping and the last product, against the oracle
+    rows = (0, 47, 48, 55, 56, 111, 112, B - 1)
     for r in rows:
         got = ab[r, :2 * n - 1].cpu().numpy().view(np.uint32)
         assert np.array_equal(got, orc.poly_multiply(ha[r], hb[r], p)), r

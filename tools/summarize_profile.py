@@ -96,13 +96,13 @@ def main():
                   "engines of 8 CUs x 4 SIMDs; SQ_ACTIVE_INST_VALU reads identical to SQ_INSTS_VALU on this stack, so it is not a "
                   "cycle count).  The butterfly mix peaks at 1 / 3.8 = 0.263 (profiles/ubench_mix_r02.txt); the counter passes run "
                   "with the profiler serialising the kernels, i.e. every kernel alone on the chip.  A wave of col_kernel_fwd walks the "
-                  "batch (16 workgroups per column tile): its per-wave figures cover 46.5 / 16 = 2.9 products.\n")
+                  "batch (16 workgroups per column tile): its per-wave figures cover 53.9 / 16 = 3.4 products.\n")
     print(open(os.path.join(dst, f"{tag}_summary.md")).read())
     # profiles/traffic.json feeds bench.py's roofline.traffic: PMC bytes per product and kernel of THIS build
     # (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md "HBM"), stamped with the sha256 of the kernel sources
     sys.path.insert(0, ROOT)
     import bench
-    units = 1024 / 22.0                                  # bench.py's default batch in 22 launch groups
+    units = 1024 / 19.0                                  # bench.py's default batch in 19 launch groups of up to 56 products
     names = {"col_kernel_fwd": "col_fwd", "col16_kernel_fwd": "col_fwd", "row_mul_kernel": "row_mul",
              "col16_kernel_inv": "col_inv", "col_kernel_inv": "col_inv"}
     traffic = {"_build": bench.kernel_source_stamp(), "_profile": tag}
@@ -110,7 +110,7 @@ def main():
         if k in names and "hbm_read_bytes_x2" in s:
             traffic[names[k]] = {"bytes_per_unit": (s["hbm_read_bytes_x2"] + s["hbm_write_bytes"]) / units,
                                  "source": f"profiles/{tag}_summary.json (FETCH_SIZE x2 + WRITE_SIZE, KiB->B), 1024 products "
-                                           "in 22 launches (46.5 per launch)"}
+                                           "in 19 launches (53.9 per launch)"}
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 
 

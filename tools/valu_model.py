@@ -34,7 +34,7 @@ FULL_RATE = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", 
              "v_cndmask_b32", "v_not_b32", "v_add_f32", "v_fma_f32", "v_accvgpr_read_b32", "v_accvgpr_write_b32",
              "v_nop"}
 
-UNITS_PER_LAUNCH = 1024 / 22.0          # bench.py's default batch in 22 launches (tools/profile.sh)
+UNITS_PER_LAUNCH = 1024 / 19.0          # bench.py's default batch in 19 launches of up to 56 products (tools/profile.sh)
 
 # (listing, substring of the mangled kernel name, SQ key in the profile summary, waves per product and pass)
 KERNELS = {
