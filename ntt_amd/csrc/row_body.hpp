@@ -21,7 +21,7 @@
 #endif
 
 #ifndef NTT_ROW_SHARE_TW
-#define NTT_ROW_SHARE_TW 1
+#define NTT_ROW_SHARE_TW 3                // bit 0: the fused kernels, bit 1: the others (Barrett, wide range)
 #endif
 #ifndef NTT_ROW_FUSE_TW
 #define NTT_ROW_FUSE_TW 15               // bits 0 / 1: first / second forward pass, 2: the inverse's first, 3: its second (A/B builds)
@@ -200,14 +200,34 @@ __device__ __forceinline__ void fused_pass2(uint32_t (&xa)[16], uint32_t (&xb)[1
     reg_ntt16_tw<MM, LAZY>(xa, roots, m, [&](int k) { return tv[k]; }, [&](int q) { return t2[q]; });
     reg_ntt16_tw<MM, LAZY>(xb, roots, m, [&](int k) { return tv[k]; }, [&](int q) { return t2[q]; });
 }
-template <class MM, bool LAZY>
+// the same for the passes that are not fused (Barrett kernels, wide-range kernels)
+template <class MM, bool LAZY, bool WIDE, int COLS>
+__device__ __forceinline__ void plain_pass2(uint32_t (&xa)[16], uint32_t (&xb)[16], const Roots64<MM> &roots, const ModParams &m,
+                                            const RowTable<typename MM::tw_t> &tab)
+{
+    using O = Ops<MM, LAZY>;
+    typename MM::tw_t tv[16];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) tv[k] = tab.template at<COLS>(k);
+    __builtin_amdgcn_sched_barrier(0);
+    reg_ntt<MM, LAZY, 4, false, true, WIDE>(xa, roots, m);
+    xa[0] = row_tighten<WIDE>(xa[0], m, O::bound(m));
+#pragma unroll
+    for (int k = 1; k < 16; ++k) xa[k] = O::mul_tw(xa[k], tv[k], m);
+    reg_ntt<MM, LAZY, 4, false, true, WIDE>(xb, roots, m);
+    xb[0] = row_tighten<WIDE>(xb[0], m, O::bound(m));
+#pragma unroll
+    for (int k = 1; k < 16; ++k) xb[k] = O::mul_tw(xb[k], tv[k], m);
+}
+template <class MM, bool LAZY, bool WIDE = false, bool FUSE = true>
 __device__ __forceinline__ void row_forward2(uint32_t (&xa)[16], uint32_t (&xb)[16], uint32_t *lds, const uint32_t t,
                                              const RowArgs<MM> &a, const ModParams &m)
 {
     using tw_t = typename MM::tw_t;
     const uint32_t b = t >> 4, i = t & 15;
     const uint32_t e1 = 272 * b + i;
-    fused_pass2<MM, LAZY, 256>(xa, xb, a.roots, m, row_table(a.twA, 16, 256, t), row_table2(a.twA2, 256, t));
+    if constexpr (FUSE) fused_pass2<MM, LAZY, 256>(xa, xb, a.roots, m, row_table(a.twA, 16, 256, t), row_table2(a.twA2, 256, t));
+    else plain_pass2<MM, LAZY, WIDE, 256>(xa, xb, a.roots, m, row_table(a.twA, 16, 256, t));
     auto exchange1 = [&](uint32_t (&x)[16]) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) NTT_LDS_ST(t + 272 * k, x[k]);
@@ -218,7 +238,8 @@ __device__ __forceinline__ void row_forward2(uint32_t (&xa)[16], uint32_t (&xb)[
     };
     exchange1(xa);
     exchange1(xb);
-    fused_pass2<MM, LAZY, 16>(xa, xb, a.roots, m, row_table(a.twB, 16, 16, i), row_table2(a.twB2, 16, i));
+    if constexpr (FUSE) fused_pass2<MM, LAZY, 16>(xa, xb, a.roots, m, row_table(a.twB, 16, 16, i), row_table2(a.twB2, 16, i));
+    else plain_pass2<MM, LAZY, WIDE, 16>(xa, xb, a.roots, m, row_table(a.twB, 16, 16, i));
     auto exchange2 = [&](uint32_t (&x)[16]) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) NTT_LDS_ST(e1 + 17 * k, x[k]);
@@ -337,6 +358,8 @@ __device__ __forceinline__ void row_mul_body(const RowArgs<MM> &a, const ModPara
     constexpr bool FUSE = row_fuse<MM, WIDE>();
     if constexpr (FUSE && NTT_ROW_SHARE_TW && (NTT_ROW_FUSE_TW & 3) == 3) {
         row_forward2<MM, LAZY>(xa, xb, lds, t, a, m);
+    } else if constexpr (!FUSE && (NTT_ROW_SHARE_TW & 2)) {
+        row_forward2<MM, LAZY, WIDE, false>(xa, xb, lds, t, a, m);
     } else {
         row_forward<MM, LAZY, WIDE, FUSE>(xa, lds, t, a, m);
         row_forward<MM, LAZY, WIDE, FUSE>(xb, lds, t, a, m);
